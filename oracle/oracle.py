@@ -1,0 +1,201 @@
+"""ctypes loader for the CPU oracle (oracle/icp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from the product package.  PARITY UNPINNED
+(see icp_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libicp_oracle.so")
+    src = os.path.join(_HERE, "icp_oracle.c")
+    hdr = os.path.join(_HERE, "icp_oracle.h")
+    stale = (not os.path.exists(so)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(so) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "libicp_oracle.so"])
+    return so
+
+
+class Config(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("tolerance", C.c_double),
+                ("min_error", C.c_double), ("initial_transform", C.c_double * 16)]
+
+
+class Result(C.Structure):
+    _fields_ = [("transformation", C.c_double * 16), ("converged", C.c_int),
+                ("num_iterations", C.c_int), ("final_error", C.c_double),
+                ("history_len", C.c_int), ("setup_seconds", C.c_double),
+                ("loop_seconds", C.c_double), ("final_seconds", C.c_double),
+                ("loop_iterations", C.c_int)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        L.orc_kdtree_build.restype = C.c_void_p
+        L.orc_kdtree_build.argtypes = [dp, C.c_int]
+        L.orc_kdtree_free.argtypes = [C.c_void_p]
+        L.orc_nearest_batch.argtypes = [C.c_void_p, dp, C.c_int, ip, dp, C.c_int]
+        L.orc_k_nearest.restype = C.c_int
+        L.orc_k_nearest.argtypes = [C.c_void_p, dp, C.c_int, ip]
+        L.orc_nearest_batch_brute.argtypes = [dp, C.c_int, dp, C.c_int, ip, dp]
+        L.orc_k_nearest_brute.restype = C.c_int
+        L.orc_k_nearest_brute.argtypes = [dp, C.c_int, dp, C.c_int, ip]
+        L.orc_estimate_normals.argtypes = [dp, C.c_int, C.c_void_p, C.c_int, dp, C.c_int]
+        L.orc_solve_point_to_plane.argtypes = [dp, dp, dp, C.c_int, dp]
+        L.orc_normal_equations.argtypes = [dp, dp, dp, C.c_int, dp]
+        L.orc_solve_from_sums.argtypes = [dp, dp]
+        L.orc_smallest_eigenvector.argtypes = [dp, dp]
+        L.orc_icp_config_default.argtypes = [C.POINTER(Config)]
+        L.orc_icp_point_to_plane.restype = C.c_int
+        L.orc_icp_point_to_plane.argtypes = [dp, C.c_int, dp, C.c_int, C.POINTER(Config), C.c_int,
+                                             C.c_int, C.c_int, C.POINTER(Result), dp, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class KDTree:
+    """kdtree.hpp:18-186"""
+
+    def __init__(self, points):
+        self.points, p = _d(points)
+        self.n = self.points.shape[0]
+        self._h = lib().orc_kdtree_build(p, self.n)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_kdtree_free(self._h)
+            self._h = None
+
+    def nearest_batch(self, queries, nthreads=1):
+        q, qp = _d(queries)
+        n = q.shape[0]
+        idx = np.empty(n, dtype=np.int32)
+        d2 = np.empty(n, dtype=np.float64)
+        lib().orc_nearest_batch(self._h, qp, n, idx.ctypes.data_as(C.POINTER(C.c_int)),
+                                d2.ctypes.data_as(C.POINTER(C.c_double)), nthreads)
+        return idx, d2
+
+    def k_nearest(self, query, k):
+        q, qp = _d(query)
+        out = np.empty(max(k, 1), dtype=np.int32)
+        c = lib().orc_k_nearest(self._h, qp, k, out.ctypes.data_as(C.POINTER(C.c_int)))
+        return out[:c].copy()
+
+
+def nearest_batch_brute(targets, queries):
+    t, tp = _d(targets)
+    q, qp = _d(queries)
+    n = q.shape[0]
+    idx = np.empty(n, dtype=np.int32)
+    d2 = np.empty(n, dtype=np.float64)
+    lib().orc_nearest_batch_brute(tp, t.shape[0], qp, n, idx.ctypes.data_as(C.POINTER(C.c_int)),
+                                  d2.ctypes.data_as(C.POINTER(C.c_double)))
+    return idx, d2
+
+
+def k_nearest_brute(targets, query, k):
+    t, tp = _d(targets)
+    q, qp = _d(query)
+    out = np.empty(max(k, 1), dtype=np.int32)
+    c = lib().orc_k_nearest_brute(tp, t.shape[0], qp, k, out.ctypes.data_as(C.POINTER(C.c_int)))
+    return out[:c].copy()
+
+
+def estimate_normals(points, tree=None, k=20, nthreads=1):
+    """icp.hpp:23-67"""
+    p, pp = _d(points)
+    tree = tree or KDTree(p)
+    out = np.empty_like(p)
+    lib().orc_estimate_normals(pp, p.shape[0], tree._h, k, out.ctypes.data_as(C.POINTER(C.c_double)),
+                               nthreads)
+    return out
+
+
+def normal_equations(source, target, normals):
+    s, sp = _d(source)
+    t, tp = _d(target)
+    n, np_ = _d(normals)
+    out = np.empty(28)
+    lib().orc_normal_equations(sp, tp, np_, s.shape[0], out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def solve_from_sums(sums):
+    s, sp = _d(sums)
+    T = np.empty(16)
+    lib().orc_solve_from_sums(sp, T.ctypes.data_as(C.POINTER(C.c_double)))
+    return T.reshape(4, 4)
+
+
+def solve_point_to_plane(source, target, normals):
+    """icp.hpp:89-144"""
+    s, sp = _d(source)
+    t, tp = _d(target)
+    n, np_ = _d(normals)
+    T = np.empty(16)
+    lib().orc_solve_point_to_plane(sp, tp, np_, s.shape[0], T.ctypes.data_as(C.POINTER(C.c_double)))
+    return T.reshape(4, 4)
+
+
+def smallest_eigenvector(cov):
+    c, cp = _d(np.asarray(cov).reshape(9))
+    v = np.empty(3)
+    lib().orc_smallest_eigenvector(cp, v.ctypes.data_as(C.POINTER(C.c_double)))
+    return v
+
+
+class ICPResult:
+    pass
+
+
+def icp_point_to_plane(source, target, max_iterations=50, tolerance=1e-6, min_error=1e-9,
+                       initial_transform=None, normal_k=20, faithful=True, nthreads=1):
+    """icp.hpp:157-258.  Returns an object with the ICPResult fields (types.hpp:155-164)
+    plus timing."""
+    s, sp = _d(source)
+    t, tp = _d(target)
+    cfg = Config()
+    lib().orc_icp_config_default(C.byref(cfg))
+    cfg.max_iterations = int(max_iterations)
+    cfg.tolerance = float(tolerance)
+    cfg.min_error = float(min_error)
+    if initial_transform is not None:
+        it = np.ascontiguousarray(initial_transform, dtype=np.float64).reshape(16)
+        for i in range(16):
+            cfg.initial_transform[i] = it[i]
+    cap = int(max_iterations) + 2
+    hist = np.zeros(cap)
+    res = Result()
+    rc = lib().orc_icp_point_to_plane(sp, s.shape[0], tp, t.shape[0], C.byref(cfg), normal_k,
+                                      1 if faithful else 0, nthreads, C.byref(res),
+                                      hist.ctypes.data_as(C.POINTER(C.c_double)), cap)
+    if rc != 0:
+        raise ValueError("oracle icp: bad input")
+    r = ICPResult()
+    r.transformation = np.array(res.transformation[:]).reshape(4, 4)
+    r.converged = bool(res.converged)
+    r.num_iterations = res.num_iterations
+    r.final_error = res.final_error
+    r.error_history = hist[:res.history_len].copy()
+    r.setup_seconds = res.setup_seconds
+    r.loop_seconds = res.loop_seconds
+    r.final_seconds = res.final_seconds
+    r.loop_iterations = res.loop_iterations
+    return r
