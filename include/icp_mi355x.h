@@ -1,0 +1,144 @@
+/*
+ * icp_mi355x.h -- C ABI of libicp_mi355x.so: point-to-plane ICP registration on one
+ * MI355X (gfx950), optionally source-sharded over several with RCCL.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference has no
+ * FFI layer; its boundary is the header-only C++ function
+ *     slam::icp_point_to_plane(const PointCloud&, const PointCloud&, const ICPConfig&)
+ *         -> ICPResult                      (slam_viz/core/icp.hpp:157-161)
+ * called from slam_node.cpp:138 and loop_closure.hpp:109.  Each entry point below
+ * names the reference interface it replaces (paths relative to
+ * slam_viz/include/slam_viz/core/).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - points: row-major N x 3 fp64, contiguous ("xyzxyz...", types.hpp:17).
+ *   - 4x4 transforms: ROW-major double[16] here.  Eigen::Matrix4d is column-major
+ *     (types.hpp:76); an adapter must convert element-wise, never memcpy.
+ *   - every function returns ICPMI_OK (0) or a negative ICPMI_ERR_* code; the text
+ *     of the last failure is available from icpmi_last_error().
+ *   - one icpmi_ctx serves one caller thread at a time; distinct contexts may run
+ *     concurrently.  Calls block until results are on the host.
+ *   - there is no CPU fallback: with no usable HIP device icpmi_create fails.
+ */
+#ifndef ICP_MI355X_H
+#define ICP_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICPMI_OK 0
+#define ICPMI_ERR_NULL (-1)          /* a required pointer is NULL */
+#define ICPMI_ERR_EMPTY_SOURCE (-2)  /* n_src <= 0 (reference: division by zero, icp.hpp:206) */
+#define ICPMI_ERR_EMPTY_TARGET (-3)  /* n_tgt <= 0 (reference: row(-1) UB, kdtree.hpp:33-36,211) */
+#define ICPMI_ERR_CAPACITY (-4)      /* error_history buffer smaller than max_iterations + 1 */
+#define ICPMI_ERR_HIP (-5)           /* HIP runtime failure */
+#define ICPMI_ERR_RCCL (-6)          /* RCCL failure */
+#define ICPMI_ERR_ARG (-7)           /* argument out of range */
+#define ICPMI_ERR_NO_DEVICE (-8)     /* no gfx950 device / kernels not loadable */
+
+/* nearest-neighbour search engines (all return the exact fp64 nearest neighbour) */
+#define ICPMI_SEARCH_AUTO 0
+#define ICPMI_SEARCH_EXACT_F64 1     /* fp64 brute force, SGPR-broadcast targets */
+#define ICPMI_SEARCH_MFMA_F32 2      /* fp32 MFMA coarse pass + certified fp64 recheck */
+
+typedef struct icpmi_ctx icpmi_ctx;
+
+typedef struct {
+    int32_t device;     /* HIP device ordinal */
+    int32_t normal_k;   /* neighbours for PCA normals; the reference hard-codes 20 (icp.hpp:170) */
+    int32_t search;     /* ICPMI_SEARCH_* */
+    int32_t profile;    /* non-zero: bracket kernels with HIP events (icpmi_get_profile) */
+} icpmi_options;
+
+/* mirrors slam::ICPConfig, types.hpp:143-148 */
+typedef struct {
+    int32_t max_iterations;        /* default 50 */
+    int32_t reserved;
+    double tolerance;              /* default 1e-6 */
+    double min_error;              /* default 1e-9 */
+    double initial_transform[16];  /* row-major, default identity */
+} icpmi_config;
+
+/* mirrors slam::ICPResult, types.hpp:155-164 */
+typedef struct {
+    double transformation[16];     /* row-major, maps source -> target (icp.hpp:154-155) */
+    int32_t converged;
+    int32_t num_iterations;        /* error_history.size() - 1 (icp.hpp:255) */
+    double final_error;
+    int32_t history_len;           /* entries written to error_history */
+    int32_t loop_iterations;       /* loop bodies entered (not a reference field) */
+} icpmi_result;
+
+/* per-stage device time from HIP events on the library's stream, accumulated since
+ * the last icpmi_reset_profile(); only filled when options.profile != 0 */
+typedef struct {
+    double nn_ms;        int64_t nn_launches;        /* correspondence search passes */
+    double reduce_ms;    int64_t reduce_launches;    /* residual + 6x6 accumulation + solve */
+    double transform_ms; int64_t transform_launches;
+    double normals_ms;   int64_t normals_launches;   /* k-NN + PCA */
+    double nn_pairs;                                 /* (source,target) pairs evaluated by nn passes */
+    int64_t nn_recheck_queries;                      /* queries re-resolved in fp64 (MFMA engine) */
+    int64_t nn_fallback_queries;                     /* queries sent to the fp64 exhaustive fallback */
+} icpmi_profile;
+
+void icpmi_options_default(icpmi_options *opt);
+void icpmi_config_default(icpmi_config *cfg);        /* types.hpp:143-148 defaults */
+
+int icpmi_create(const icpmi_options *opt, icpmi_ctx **out);
+void icpmi_destroy(icpmi_ctx *ctx);
+const char *icpmi_last_error(const icpmi_ctx *ctx);  /* ctx may be NULL: last create error */
+const char *icpmi_version(void);
+
+/* Replaces slam::icp_point_to_plane (icp.hpp:157-258).  Host pointers.
+ * error_history must hold max_iterations + 1 doubles (history_cap states its size). */
+int icpmi_align(icpmi_ctx *ctx, const double *source_xyz, int64_t n_src,
+                const double *target_xyz, int64_t n_tgt, const icpmi_config *cfg,
+                icpmi_result *result, double *error_history, int32_t history_cap);
+
+/* Same, with source/target already resident in this device's HBM (device pointers). */
+int icpmi_align_device(icpmi_ctx *ctx, const double *d_source_xyz, int64_t n_src,
+                       const double *d_target_xyz, int64_t n_tgt, const icpmi_config *cfg,
+                       icpmi_result *result, double *error_history, int32_t history_cap);
+
+/* Replaces KDTree(points) + KDTree::nearest_batch (kdtree.hpp:20-26,43-59): for each
+ * query the index of, and squared distance to, its nearest target.  Host pointers;
+ * dist_sq may be NULL. */
+int icpmi_nearest_batch(icpmi_ctx *ctx, const double *targets_xyz, int64_t n_tgt,
+                        const double *queries_xyz, int64_t n_qry, int32_t *indices,
+                        double *dist_sq);
+
+/* Replaces estimate_normals(points, tree, k) (icp.hpp:23-67).  Host pointers. */
+int icpmi_estimate_normals(icpmi_ctx *ctx, const double *points_xyz, int64_t n, int32_t k,
+                           double *normals_xyz);
+
+/* Replaces solve_point_to_plane(source, target, normals) (icp.hpp:89-144): inputs are
+ * three n x 3 arrays matched row by row; out is the row-major 4x4 update. */
+int icpmi_solve_point_to_plane(icpmi_ctx *ctx, const double *source_xyz,
+                               const double *target_xyz, const double *normals_xyz, int64_t n,
+                               double transform_out[16]);
+
+/* Replaces Transformation::apply(cloud) (types.hpp:110-115): out = in * R^T + t^T. */
+int icpmi_transform_points(icpmi_ctx *ctx, const double transform[16], const double *in_xyz,
+                           int64_t n, double *out_xyz);
+
+/* Multi-GPU (new; the reference has no distributed path).  One process per GPU.  Rank 0
+ * obtains an id, the host distributes it (e.g. torch.distributed broadcast), every rank
+ * calls icpmi_comm_init.  Afterwards icpmi_align* treats `source` as this rank's shard
+ * of the source cloud; the target is replicated.  Each iteration all-reduces 29 doubles
+ * (21 J^T J + 6 J^T b + sum b^2 + count) over RCCL. */
+#define ICPMI_UNIQUE_ID_BYTES 128
+int icpmi_comm_unique_id(icpmi_ctx *ctx, void *id_out /* ICPMI_UNIQUE_ID_BYTES */);
+int icpmi_comm_init(icpmi_ctx *ctx, int32_t n_ranks, int32_t rank, const void *id);
+int icpmi_comm_finalize(icpmi_ctx *ctx);
+
+/* profiling */
+int icpmi_reset_profile(icpmi_ctx *ctx);
+int icpmi_get_profile(icpmi_ctx *ctx, icpmi_profile *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,218 @@
+"""ctypes binding of include/icp_mi355x.h (the C ABI of libicp_mi355x.so).
+
+The library is the product; there is deliberately no Python or CPU fallback here:
+if the shared object is missing or no gfx950 device is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+OK = 0
+ERR_NULL, ERR_EMPTY_SOURCE, ERR_EMPTY_TARGET, ERR_CAPACITY = -1, -2, -3, -4
+ERR_HIP, ERR_RCCL, ERR_ARG, ERR_NO_DEVICE = -5, -6, -7, -8
+SEARCH_AUTO, SEARCH_EXACT_F64, SEARCH_MFMA_F32 = 0, 1, 2
+UNIQUE_ID_BYTES = 128
+
+EXPORTS = [
+    "icpmi_version", "icpmi_options_default", "icpmi_config_default", "icpmi_create",
+    "icpmi_destroy", "icpmi_last_error", "icpmi_align", "icpmi_align_device",
+    "icpmi_nearest_batch", "icpmi_estimate_normals", "icpmi_solve_point_to_plane",
+    "icpmi_transform_points", "icpmi_comm_unique_id", "icpmi_comm_init", "icpmi_comm_finalize",
+    "icpmi_reset_profile", "icpmi_get_profile",
+]
+
+
+class Options(C.Structure):
+    _fields_ = [("device", C.c_int32), ("normal_k", C.c_int32), ("search", C.c_int32),
+                ("profile", C.c_int32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("reserved", C.c_int32),
+                ("tolerance", C.c_double), ("min_error", C.c_double),
+                ("initial_transform", C.c_double * 16)]
+
+
+class Result(C.Structure):
+    _fields_ = [("transformation", C.c_double * 16), ("converged", C.c_int32),
+                ("num_iterations", C.c_int32), ("final_error", C.c_double),
+                ("history_len", C.c_int32), ("loop_iterations", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("nn_ms", C.c_double), ("nn_launches", C.c_int64),
+                ("reduce_ms", C.c_double), ("reduce_launches", C.c_int64),
+                ("transform_ms", C.c_double), ("transform_launches", C.c_int64),
+                ("normals_ms", C.c_double), ("normals_launches", C.c_int64),
+                ("nn_pairs", C.c_double), ("nn_recheck_queries", C.c_int64),
+                ("nn_fallback_queries", C.c_int64)]
+
+
+class IcpError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("icp_mi355x error %d: %s" % (code, message))
+        self.code = code
+
+
+_LIB = None
+
+
+def load_library(path=None):
+    """dlopen the in-tree libicp_mi355x.so (must have been built: see build.build_library)."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    path = path or _build.LIB_PATH
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % path)
+    L = C.CDLL(path)
+    dp, vp = C.POINTER(C.c_double), C.c_void_p
+    L.icpmi_version.restype = C.c_char_p
+    L.icpmi_options_default.argtypes = [C.POINTER(Options)]
+    L.icpmi_config_default.argtypes = [C.POINTER(Config)]
+    L.icpmi_create.argtypes = [C.POINTER(Options), C.POINTER(vp)]
+    L.icpmi_destroy.argtypes = [vp]
+    L.icpmi_destroy.restype = None
+    L.icpmi_last_error.argtypes = [vp]
+    L.icpmi_last_error.restype = C.c_char_p
+    L.icpmi_align.argtypes = [vp, dp, C.c_int64, dp, C.c_int64, C.POINTER(Config),
+                              C.POINTER(Result), dp, C.c_int32]
+    L.icpmi_align_device.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.POINTER(Config),
+                                     C.POINTER(Result), dp, C.c_int32]
+    L.icpmi_nearest_batch.argtypes = [vp, dp, C.c_int64, dp, C.c_int64, C.POINTER(C.c_int32), dp]
+    L.icpmi_estimate_normals.argtypes = [vp, dp, C.c_int64, C.c_int32, dp]
+    L.icpmi_solve_point_to_plane.argtypes = [vp, dp, dp, dp, C.c_int64, dp]
+    L.icpmi_transform_points.argtypes = [vp, dp, dp, C.c_int64, dp]
+    L.icpmi_comm_unique_id.argtypes = [vp, vp]
+    L.icpmi_comm_init.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    L.icpmi_comm_finalize.argtypes = [vp]
+    L.icpmi_reset_profile.argtypes = [vp]
+    L.icpmi_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    for name in EXPORTS:
+        getattr(L, name)  # raises AttributeError if a declared symbol is not exported
+    _LIB = L
+    return L
+
+
+def _f64(a, cols=3):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if cols and (a.ndim != 2 or a.shape[1] != cols):
+        raise ValueError("expected an N x %d array" % cols)
+    return a
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context:
+    """One icpmi_ctx: a device, a stream and its workspace."""
+
+    def __init__(self, device=0, normal_k=20, search=SEARCH_AUTO, profile=False):
+        self._lib = load_library()
+        opt = Options()
+        self._lib.icpmi_options_default(C.byref(opt))
+        opt.device, opt.normal_k, opt.search, opt.profile = device, normal_k, search, int(profile)
+        h = C.c_void_p()
+        rc = self._lib.icpmi_create(C.byref(opt), C.byref(h))
+        if rc != OK:
+            raise IcpError(rc, self._lib.icpmi_last_error(None).decode())
+        self._h = h
+        self.n_ranks, self.rank = 1, 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.icpmi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != OK:
+            raise IcpError(rc, self._lib.icpmi_last_error(self._h).decode())
+
+    @staticmethod
+    def make_config(max_iterations=50, tolerance=1e-6, min_error=1e-9, initial_transform=None):
+        cfg = Config()
+        cfg.max_iterations, cfg.tolerance, cfg.min_error = int(max_iterations), tolerance, min_error
+        it = np.eye(4) if initial_transform is None else np.asarray(initial_transform, dtype=np.float64)
+        for i, v in enumerate(it.reshape(16)):
+            cfg.initial_transform[i] = v
+        return cfg
+
+    def align(self, source, target, cfg):
+        src, tgt = _f64(source), _f64(target)
+        cap = cfg.max_iterations + 1
+        hist = np.zeros(max(cap, 1))
+        res = Result()
+        self._check(self._lib.icpmi_align(self._h, _dp(src), src.shape[0], _dp(tgt), tgt.shape[0],
+                                          C.byref(cfg), C.byref(res), _dp(hist), cap))
+        return res, hist[:res.history_len].copy()
+
+    def align_device(self, src_ptr, n_src, tgt_ptr, n_tgt, cfg):
+        """src_ptr/tgt_ptr: device addresses of row-major N x 3 fp64 (e.g. tensor.data_ptr())."""
+        cap = cfg.max_iterations + 1
+        hist = np.zeros(max(cap, 1))
+        res = Result()
+        self._check(self._lib.icpmi_align_device(self._h, C.c_void_p(src_ptr), n_src,
+                                                 C.c_void_p(tgt_ptr), n_tgt, C.byref(cfg),
+                                                 C.byref(res), _dp(hist), cap))
+        return res, hist[:res.history_len].copy()
+
+    def nearest_batch(self, targets, queries, want_dist=True):
+        tgt, qry = _f64(targets), _f64(queries)
+        idx = np.empty(qry.shape[0], dtype=np.int32)
+        d2 = np.empty(qry.shape[0]) if want_dist else None
+        self._check(self._lib.icpmi_nearest_batch(
+            self._h, _dp(tgt), tgt.shape[0], _dp(qry), qry.shape[0],
+            idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(d2) if want_dist else None))
+        return idx, d2
+
+    def estimate_normals(self, points, k=20):
+        pts = _f64(points)
+        out = np.empty_like(pts)
+        self._check(self._lib.icpmi_estimate_normals(self._h, _dp(pts), pts.shape[0], k, _dp(out)))
+        return out
+
+    def solve_point_to_plane(self, source, target, normals):
+        s, t, n = _f64(source), _f64(target), _f64(normals)
+        if not (s.shape == t.shape == n.shape):
+            raise ValueError("source, target and normals must have the same shape")
+        T = np.empty(16)
+        self._check(self._lib.icpmi_solve_point_to_plane(self._h, _dp(s), _dp(t), _dp(n), s.shape[0], _dp(T)))
+        return T.reshape(4, 4)
+
+    def transform_points(self, T, points):
+        pts = _f64(points)
+        Tm = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+        out = np.empty_like(pts)
+        self._check(self._lib.icpmi_transform_points(self._h, _dp(Tm), _dp(pts), pts.shape[0], _dp(out)))
+        return out
+
+    # multi-GPU
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        self._check(self._lib.icpmi_comm_unique_id(self._h, buf))
+        return buf.raw
+
+    def comm_init(self, n_ranks, rank, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES) if unique_id else None
+        self._check(self._lib.icpmi_comm_init(self._h, n_ranks, rank, buf))
+        self.n_ranks, self.rank = n_ranks, rank
+
+    def comm_finalize(self):
+        self._check(self._lib.icpmi_comm_finalize(self._h))
+        self.n_ranks, self.rank = 1, 0
+
+    def reset_profile(self):
+        self._check(self._lib.icpmi_reset_profile(self._h))
+
+    def get_profile(self):
+        p = Profile()
+        self._check(self._lib.icpmi_get_profile(self._h, C.byref(p)))
+        return {f[0]: getattr(p, f[0]) for f in Profile._fields_}

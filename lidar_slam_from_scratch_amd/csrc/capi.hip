@@ -1,0 +1,685 @@
+// capi.hip -- host side of libicp_mi355x.so: the C ABI declared in include/icp_mi355x.h.
+//
+// Orchestrates the kernels of kernels.h on one HIP stream per context.  The ICP loop
+// (icp.hpp:181-232) runs device-side: the error, both convergence tests, the 6x6 solve
+// and the pose accumulation are done by k_finish_step, and once the loop has ended the
+// remaining queued kernels return at their first instruction.  The host only looks at a
+// 4-byte flag, two iterations behind the launch front, to stop queueing.
+//
+// There is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/icp_mi355x.h"
+#include "kernels.h"
+
+using namespace icpmi;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int stage;
+};
+
+enum Stage { ST_NN = 0, ST_REDUCE = 1, ST_TRANSFORM = 2, ST_NORMALS = 3, ST_COUNT = 4 };
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+} // namespace
+
+struct icpmi_ctx {
+    icpmi_options opt;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int cu_count = 256;
+
+    DevBuf cur, nrm, idx, part_d2, part_idx, partials, history, stage_a, stage_b, stage_c, d2out;
+    IcpState *d_state = nullptr;
+    IcpState *h_state = nullptr;   // pinned
+    int32_t *h_flags = nullptr;    // pinned ring of done flags
+    std::vector<hipEvent_t> flag_events;
+
+    // profiling
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    icpmi_profile prof;
+
+    // multi-GPU
+    Rccl rccl;
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0;
+};
+
+namespace {
+
+constexpr int kFlagRing = 8;
+constexpr int kLag = 2;
+
+int fail(icpmi_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                    \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ctx, ICPMI_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                   \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                           \
+    } while (0)
+
+int reserve(icpmi_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return ICPMI_OK;
+    if (b.p) HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = std::max(bytes, (size_t)4096);
+    want = want + want / 4; // grow-only with slack: odometry clouds vary frame to frame
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return ICPMI_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+// ---- profiling helpers ----------------------------------------------------------------
+struct StageTimer {
+    icpmi_ctx *ctx;
+    EventPair *ep = nullptr;
+    StageTimer(icpmi_ctx *c, int stage) : ctx(c)
+    {
+        if (!ctx->opt.profile) return;
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            EventPair p;
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            p.stage = stage;
+            ctx->ev_pool.push_back(p);
+        }
+        ep = &ctx->ev_pool[ctx->ev_used++];
+        ep->stage = stage;
+        (void)hipEventRecord(ep->a, ctx->stream);
+    }
+    ~StageTimer()
+    {
+        if (ep) (void)hipEventRecord(ep->b, ctx->stream);
+    }
+};
+
+// call after the stream has been synchronised
+void harvest_profile(icpmi_ctx *ctx)
+{
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        float ms = 0.f;
+        EventPair &p = ctx->ev_pool[i];
+        if (hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) continue;
+        switch (p.stage) {
+        case ST_NN: ctx->prof.nn_ms += ms; ctx->prof.nn_launches++; break;
+        case ST_REDUCE: ctx->prof.reduce_ms += ms; ctx->prof.reduce_launches++; break;
+        case ST_TRANSFORM: ctx->prof.transform_ms += ms; ctx->prof.transform_launches++; break;
+        case ST_NORMALS: ctx->prof.normals_ms += ms; ctx->prof.normals_launches++; break;
+        default: break;
+        }
+    }
+    ctx->ev_used = 0;
+}
+
+// ---- kernel launch wrappers ------------------------------------------------------------
+
+// nearest neighbour of every row of d_qry among d_tgt -> d_idx (+ optional d_d2)
+int launch_nn(icpmi_ctx *ctx, const double *d_qry, int n, const double *d_tgt, int m, int *d_idx,
+              double *d_d2, const IcpState *st)
+{
+    constexpr int QPT = 2;
+    const int qblocks = (n + 256 * QPT - 1) / (256 * QPT);
+    // enough workgroups to fill 256 CUs several times over; every split keeps >= 256 targets
+    int splits = (8 * ctx->cu_count + qblocks - 1) / qblocks;
+    splits = std::max(1, std::min(splits, std::min(64, (m + 255) / 256)));
+    const int per = (m + splits - 1) / splits;
+    splits = (m + per - 1) / per;
+    int rc;
+    if ((rc = reserve(ctx, ctx->part_d2, sizeof(double) * (size_t)splits * n))) return rc;
+    if ((rc = reserve(ctx, ctx->part_idx, sizeof(int) * (size_t)splits * n))) return rc;
+    StageTimer t(ctx, ST_NN);
+    hipLaunchKernelGGL(k_nn_f64<QPT>, dim3(qblocks, splits), dim3(256), 0, ctx->stream, d_qry, n,
+                       d_tgt, m, per, (double *)ctx->part_d2.p, (int *)ctx->part_idx.p, st);
+    hipLaunchKernelGGL(k_nn_merge, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const double *)ctx->part_d2.p, (const int *)ctx->part_idx.p, n, splits,
+                       d_idx, d_d2, st);
+    ctx->prof.nn_pairs += (double)n * (double)m;
+    HIP_TRY(ctx, hipGetLastError());
+    return ICPMI_OK;
+}
+
+int reduce_blocks(const icpmi_ctx *ctx, int n)
+{
+    return std::max(1, std::min(ctx->cu_count, (n + 255) / 256));
+}
+
+int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, int row1,
+                   double *d_normals)
+{
+    constexpr int BLOCK = 128;
+    const int rows = row1 - row0;
+    if (rows <= 0) return ICPMI_OK;
+    const size_t smem = (size_t)k * BLOCK * (sizeof(double) + sizeof(int));
+    StageTimer t(ctx, ST_NORMALS);
+    hipLaunchKernelGGL(k_knn_normals<BLOCK>, dim3((rows + BLOCK - 1) / BLOCK), dim3(BLOCK), smem,
+                       ctx->stream, d_pts, m, k, row0, row1, d_normals);
+    HIP_TRY(ctx, hipGetLastError());
+    return ICPMI_OK;
+}
+
+int check_common(icpmi_ctx *ctx)
+{
+    if (!ctx) return ICPMI_ERR_NULL;
+    HIP_TRY(ctx, hipSetDevice(ctx->opt.device));
+    return ICPMI_OK;
+}
+
+int load_rccl(icpmi_ctx *ctx)
+{
+    Rccl &r = ctx->rccl;
+    if (r.lib) return ICPMI_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+        r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return fail(ctx, ICPMI_ERR_RCCL, "cannot dlopen librccl: %s", dlerror());
+#define SYM(field, name)                                                                      \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name));                        \
+    if (!r.field) return fail(ctx, ICPMI_ERR_RCCL, "librccl lacks %s", name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(AllGather, "ncclAllGather");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return ICPMI_OK;
+}
+
+#define RCCL_TRY(ctx, expr)                                                                   \
+    do {                                                                                      \
+        ncclResult_t r_ = (expr);                                                             \
+        if (r_ != ncclSuccess)                                                                \
+            return fail(ctx, ICPMI_ERR_RCCL, "%s failed: %s", #expr,                          \
+                        ctx->rccl.GetErrorString(r_));                                        \
+    } while (0)
+
+// ---- the ICP call, device pointers -----------------------------------------------------
+int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const double *d_tgt,
+                 int64_t n_tgt64, const icpmi_config *cfg, icpmi_result *result,
+                 double *error_history, int32_t history_cap)
+{
+    const int n = (int)n_src64, m = (int)n_tgt64;
+    const int max_it = cfg->max_iterations;
+    const int max_hist = max_it + 1;
+    hipStream_t s = ctx->stream;
+    int rc;
+
+    if ((rc = reserve(ctx, ctx->cur, sizeof(double) * 3 * (size_t)n))) return rc;
+    if ((rc = reserve(ctx, ctx->nrm, sizeof(double) * 3 * (size_t)m))) return rc;
+    if ((rc = reserve(ctx, ctx->idx, sizeof(int) * (size_t)n))) return rc;
+    const int rblocks = reduce_blocks(ctx, n);
+    if ((rc = reserve(ctx, ctx->partials, sizeof(double) * kSumsStride * (size_t)rblocks))) return rc;
+    if ((rc = reserve(ctx, ctx->history, sizeof(double) * (size_t)(max_hist + 1)))) return rc;
+
+    double *cur = (double *)ctx->cur.p;
+    double *nrm = (double *)ctx->nrm.p;
+    int *idx = (int *)ctx->idx.p;
+    double *partials = (double *)ctx->partials.p;
+    double *hist = (double *)ctx->history.p;
+
+    // state: total = initial_transform (icp.hpp:163,178), prev_error = DBL_MAX (icp.hpp:179)
+    IcpState *hs = ctx->h_state;
+    memset(hs, 0, sizeof(*hs));
+    memcpy(hs->total, cfg->initial_transform, sizeof(double) * 16);
+    hs->prev_error = 1.7976931348623157e308;
+    hs->tolerance = cfg->tolerance;
+    hs->min_error = cfg->min_error;
+    hs->max_hist = max_hist;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state, hs, sizeof(IcpState), hipMemcpyHostToDevice, s));
+
+    // normals of the target (icp.hpp:169-171).  With several ranks each computes a slice of
+    // rows against the full target and the slices are all-gathered.
+    if (ctx->n_ranks > 1) {
+        const int per = (m + ctx->n_ranks - 1) / ctx->n_ranks;
+        if ((rc = reserve(ctx, ctx->stage_a, sizeof(double) * 3 * (size_t)per * ctx->n_ranks))) return rc;
+        double *gathered = (double *)ctx->stage_a.p;
+        const int row0 = std::min(m, ctx->rank * per), row1 = std::min(m, row0 + per);
+        // rows land at their global offset inside `gathered`, so the gather is in place
+        if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, row0, row1, gathered))) return rc;
+        RCCL_TRY(ctx, ctx->rccl.AllGather(gathered + 3 * (size_t)ctx->rank * per, gathered,
+                                          3 * (size_t)per, ncclDouble, ctx->comm, s));
+        HIP_TRY(ctx, hipMemcpyAsync(nrm, gathered, sizeof(double) * 3 * (size_t)m,
+                                    hipMemcpyDeviceToDevice, s));
+    } else {
+        if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, 0, m, nrm))) return rc;
+    }
+
+    // current_source = source * R0^T + t0^T (icp.hpp:174-176)
+    {
+        StageTimer t(ctx, ST_TRANSFORM);
+        hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, d_src,
+                           cur, n, ctx->d_state, 1, 0);
+    }
+
+    auto iteration = [&](int final_pass) -> int {
+        int r2;
+        if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, ctx->d_state))) return r2;
+        {
+            StageTimer t(ctx, ST_REDUCE);
+            hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, cur, n, d_tgt, nrm, idx,
+                               partials, ctx->d_state);
+            if (ctx->n_ranks > 1) {
+                hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, partials, rblocks, n,
+                                   ctx->d_state);
+                RCCL_TRY(ctx, ctx->rccl.AllReduce(ctx->d_state->sums, ctx->d_state->sums, kNumSums,
+                                                  ncclDouble, ncclSum, ctx->comm, s));
+                hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, ctx->d_state, hist, final_pass);
+            } else {
+                hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(256), 0, s, partials, rblocks, n,
+                                   ctx->d_state, hist, final_pass);
+            }
+        }
+        if (!final_pass) {
+            StageTimer t(ctx, ST_TRANSFORM);
+            hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
+                               cur, cur, n, ctx->d_state, 0, 1);
+        }
+        return ICPMI_OK;
+    };
+
+    for (int it = 0; it < max_it; ++it) {
+        if (it >= kLag) {
+            const int slot = (it - kLag) % kFlagRing;
+            HIP_TRY(ctx, hipEventSynchronize(ctx->flag_events[slot]));
+            if (ctx->h_flags[slot]) break; // loop already left on the device
+        }
+        if ((rc = iteration(0))) return rc;
+        const int slot = it % kFlagRing;
+        HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_flags[slot], &ctx->d_state->done, sizeof(int32_t),
+                                    hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipEventRecord(ctx->flag_events[slot], s));
+    }
+    // post-loop evaluation (icp.hpp:235-252): a full pass after exhaustion, a re-statement
+    // of the last error after a convergence break
+    if ((rc = iteration(1))) return rc;
+
+    HIP_TRY(ctx, hipMemcpyAsync(hs, ctx->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipGetLastError());
+    const int hl = std::min(hs->hist_len, max_hist);
+    if (hl > 0)
+        HIP_TRY(ctx, hipMemcpy(error_history, hist, sizeof(double) * (size_t)std::min(hl, history_cap),
+                               hipMemcpyDeviceToHost));
+    harvest_profile(ctx);
+
+    memcpy(result->transformation, hs->total, sizeof(double) * 16); // icp.hpp:254
+    result->converged = hs->converged;
+    result->num_iterations = hs->hist_len - 1;                      // icp.hpp:255
+    result->final_error = hs->final_error;
+    result->history_len = hl;
+    result->loop_iterations = hs->loops;
+    return ICPMI_OK;
+}
+
+int validate_align(icpmi_ctx *ctx, const void *src, int64_t n_src, const void *tgt, int64_t n_tgt,
+                   const icpmi_config *cfg, icpmi_result *result, double *hist, int32_t cap)
+{
+    if (!ctx) return ICPMI_ERR_NULL;
+    if (!src || !tgt || !cfg || !result || !hist) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n_src <= 0) return fail(ctx, ICPMI_ERR_EMPTY_SOURCE, "empty source cloud");
+    if (n_tgt <= 0) return fail(ctx, ICPMI_ERR_EMPTY_TARGET, "empty target cloud");
+    if (n_src > (int64_t)700000000 || n_tgt > (int64_t)700000000)
+        return fail(ctx, ICPMI_ERR_ARG, "cloud larger than 7e8 points");
+    if (cfg->max_iterations < 0) return fail(ctx, ICPMI_ERR_ARG, "max_iterations < 0");
+    if (cap < cfg->max_iterations + 1)
+        return fail(ctx, ICPMI_ERR_CAPACITY, "error_history holds %d entries, needs %d", cap,
+                    cfg->max_iterations + 1);
+    return ICPMI_OK;
+}
+
+} // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char *icpmi_version(void) { return "icp_mi355x 0.1 (gfx950)"; }
+
+void icpmi_options_default(icpmi_options *opt)
+{
+    if (!opt) return;
+    opt->device = 0;
+    opt->normal_k = 20; // icp.hpp:170
+    opt->search = ICPMI_SEARCH_AUTO;
+    opt->profile = 0;
+}
+
+void icpmi_config_default(icpmi_config *cfg)
+{
+    if (!cfg) return;
+    cfg->max_iterations = 50; // types.hpp:144
+    cfg->reserved = 0;
+    cfg->tolerance = 1e-6;    // types.hpp:145
+    cfg->min_error = 1e-9;    // types.hpp:146
+    for (int i = 0; i < 16; ++i) cfg->initial_transform[i] = (i % 5 == 0) ? 1.0 : 0.0;
+}
+
+int icpmi_create(const icpmi_options *opt, icpmi_ctx **out)
+{
+    if (!out) return fail(nullptr, ICPMI_ERR_NULL, "out is NULL");
+    *out = nullptr;
+    icpmi_options o;
+    if (opt) o = *opt;
+    else icpmi_options_default(&o);
+    if (o.normal_k < 1 || o.normal_k > 64)
+        return fail(nullptr, ICPMI_ERR_ARG, "normal_k %d outside [1,64]", o.normal_k);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(nullptr, ICPMI_ERR_NO_DEVICE, "no HIP device visible");
+    if (o.device < 0 || o.device >= count)
+        return fail(nullptr, ICPMI_ERR_ARG, "device %d outside [0,%d)", o.device, count);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, o.device) != hipSuccess)
+        return fail(nullptr, ICPMI_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, ICPMI_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only",
+                    o.device, prop.gcnArchName);
+    icpmi_ctx *ctx = new icpmi_ctx();
+    ctx->opt = o;
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    memset(&ctx->prof, 0, sizeof(ctx->prof));
+    auto bail = [&](const char *what) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(hipGetLastError());
+        icpmi_destroy(ctx);
+        return ICPMI_ERR_HIP;
+    };
+    if (hipSetDevice(o.device) != hipSuccess) return bail("hipSetDevice");
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
+    if (hipMalloc((void **)&ctx->d_state, sizeof(IcpState)) != hipSuccess) return bail("hipMalloc state");
+    if (hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
+    if (hipHostMalloc((void **)&ctx->h_flags, sizeof(int32_t) * kFlagRing, hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
+    memset(ctx->h_flags, 0, sizeof(int32_t) * kFlagRing);
+    ctx->flag_events.resize(kFlagRing);
+    for (int i = 0; i < kFlagRing; ++i) {
+        ctx->flag_events[i] = nullptr;
+        if (hipEventCreateWithFlags(&ctx->flag_events[i], hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
+    }
+    *out = ctx;
+    return ICPMI_OK;
+}
+
+void icpmi_destroy(icpmi_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->opt.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
+    for (DevBuf *b : {&ctx->cur, &ctx->nrm, &ctx->idx, &ctx->part_d2, &ctx->part_idx, &ctx->partials,
+                      &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out})
+        release(*b);
+    if (ctx->d_state) (void)hipFree(ctx->d_state);
+    if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    for (hipEvent_t e : ctx->flag_events)
+        if (e) (void)hipEventDestroy(e);
+    for (EventPair &p : ctx->ev_pool) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *icpmi_last_error(const icpmi_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int icpmi_align_device(icpmi_ctx *ctx, const double *d_source_xyz, int64_t n_src,
+                       const double *d_target_xyz, int64_t n_tgt, const icpmi_config *cfg,
+                       icpmi_result *result, double *error_history, int32_t history_cap)
+{
+    int rc = validate_align(ctx, d_source_xyz, n_src, d_target_xyz, n_tgt, cfg, result,
+                            error_history, history_cap);
+    if (rc) return rc;
+    if ((rc = check_common(ctx))) return rc;
+    return align_device(ctx, d_source_xyz, n_src, d_target_xyz, n_tgt, cfg, result, error_history,
+                        history_cap);
+}
+
+int icpmi_align(icpmi_ctx *ctx, const double *source_xyz, int64_t n_src, const double *target_xyz,
+                int64_t n_tgt, const icpmi_config *cfg, icpmi_result *result,
+                double *error_history, int32_t history_cap)
+{
+    int rc = validate_align(ctx, source_xyz, n_src, target_xyz, n_tgt, cfg, result, error_history,
+                            history_cap);
+    if (rc) return rc;
+    if ((rc = check_common(ctx))) return rc;
+    if ((rc = reserve(ctx, ctx->stage_b, sizeof(double) * 3 * (size_t)n_src))) return rc;
+    if ((rc = reserve(ctx, ctx->stage_c, sizeof(double) * 3 * (size_t)n_tgt))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_b.p, source_xyz, sizeof(double) * 3 * (size_t)n_src,
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.p, target_xyz, sizeof(double) * 3 * (size_t)n_tgt,
+                                hipMemcpyHostToDevice, ctx->stream));
+    return align_device(ctx, (const double *)ctx->stage_b.p, n_src, (const double *)ctx->stage_c.p,
+                        n_tgt, cfg, result, error_history, history_cap);
+}
+
+int icpmi_nearest_batch(icpmi_ctx *ctx, const double *targets_xyz, int64_t n_tgt,
+                        const double *queries_xyz, int64_t n_qry, int32_t *indices, double *dist_sq)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!targets_xyz || !queries_xyz || !indices) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n_tgt <= 0) return fail(ctx, ICPMI_ERR_EMPTY_TARGET, "empty target cloud");
+    if (n_qry < 0) return fail(ctx, ICPMI_ERR_ARG, "n_qry < 0");
+    if (n_qry == 0) return ICPMI_OK;
+    const int n = (int)n_qry, m = (int)n_tgt;
+    if ((rc = reserve(ctx, ctx->stage_b, sizeof(double) * 3 * (size_t)n))) return rc;
+    if ((rc = reserve(ctx, ctx->stage_c, sizeof(double) * 3 * (size_t)m))) return rc;
+    if ((rc = reserve(ctx, ctx->idx, sizeof(int) * (size_t)n))) return rc;
+    if ((rc = reserve(ctx, ctx->d2out, sizeof(double) * (size_t)n))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_b.p, queries_xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.p, targets_xyz, sizeof(double) * 3 * (size_t)m, hipMemcpyHostToDevice, s));
+    if ((rc = launch_nn(ctx, (const double *)ctx->stage_b.p, n, (const double *)ctx->stage_c.p, m,
+                        (int *)ctx->idx.p, (double *)ctx->d2out.p, nullptr)))
+        return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(indices, ctx->idx.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+    if (dist_sq)
+        HIP_TRY(ctx, hipMemcpyAsync(dist_sq, ctx->d2out.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    harvest_profile(ctx);
+    return ICPMI_OK;
+}
+
+int icpmi_estimate_normals(icpmi_ctx *ctx, const double *points_xyz, int64_t n, int32_t k,
+                           double *normals_xyz)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!points_xyz || !normals_xyz) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n <= 0) return fail(ctx, ICPMI_ERR_EMPTY_TARGET, "empty cloud");
+    if (k < 1 || k > 64) return fail(ctx, ICPMI_ERR_ARG, "k %d outside [1,64]", k);
+    const int m = (int)n;
+    if ((rc = reserve(ctx, ctx->stage_c, sizeof(double) * 3 * (size_t)m))) return rc;
+    if ((rc = reserve(ctx, ctx->nrm, sizeof(double) * 3 * (size_t)m))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.p, points_xyz, sizeof(double) * 3 * (size_t)m, hipMemcpyHostToDevice, s));
+    if ((rc = launch_normals(ctx, (const double *)ctx->stage_c.p, m, k, 0, m, (double *)ctx->nrm.p))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(normals_xyz, ctx->nrm.p, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    harvest_profile(ctx);
+    return ICPMI_OK;
+}
+
+int icpmi_solve_point_to_plane(icpmi_ctx *ctx, const double *source_xyz, const double *target_xyz,
+                               const double *normals_xyz, int64_t n64, double transform_out[16])
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!source_xyz || !target_xyz || !normals_xyz || !transform_out)
+        return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n64 <= 0) return fail(ctx, ICPMI_ERR_EMPTY_SOURCE, "empty correspondence set");
+    const int n = (int)n64;
+    const size_t bytes = sizeof(double) * 3 * (size_t)n;
+    if ((rc = reserve(ctx, ctx->stage_a, bytes))) return rc;
+    if ((rc = reserve(ctx, ctx->stage_b, bytes))) return rc;
+    if ((rc = reserve(ctx, ctx->stage_c, bytes))) return rc;
+    const int rblocks = reduce_blocks(ctx, n);
+    if ((rc = reserve(ctx, ctx->partials, sizeof(double) * kSumsStride * (size_t)rblocks))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_a.p, source_xyz, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_b.p, target_xyz, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.p, normals_xyz, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(IcpState), s));
+    {
+        StageTimer t(ctx, ST_REDUCE);
+        hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, (const double *)ctx->stage_a.p, n,
+                           (const double *)ctx->stage_b.p, (const double *)ctx->stage_c.p,
+                           (const int *)nullptr, (double *)ctx->partials.p, (const IcpState *)nullptr);
+        hipLaunchKernelGGL(k_finish_solve, dim3(1), dim3(256), 0, s, (const double *)ctx->partials.p,
+                           rblocks, n, ctx->d_state);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipGetLastError());
+    harvest_profile(ctx);
+    memcpy(transform_out, ctx->h_state->delta, sizeof(double) * 16);
+    return ICPMI_OK;
+}
+
+int icpmi_transform_points(icpmi_ctx *ctx, const double transform[16], const double *in_xyz,
+                           int64_t n64, double *out_xyz)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!transform || !in_xyz || !out_xyz) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n64 < 0) return fail(ctx, ICPMI_ERR_ARG, "n < 0");
+    if (n64 == 0) return ICPMI_OK;
+    const int n = (int)n64;
+    const size_t bytes = sizeof(double) * 3 * (size_t)n;
+    if ((rc = reserve(ctx, ctx->stage_a, bytes))) return rc;
+    hipStream_t s = ctx->stream;
+    memset(ctx->h_state, 0, sizeof(IcpState));
+    memcpy(ctx->h_state->total, transform, sizeof(double) * 16);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_a.p, in_xyz, bytes, hipMemcpyHostToDevice, s));
+    {
+        StageTimer t(ctx, ST_TRANSFORM);
+        hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
+                           (const double *)ctx->stage_a.p, (double *)ctx->stage_a.p, n, ctx->d_state, 1, 0);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(out_xyz, ctx->stage_a.p, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipGetLastError());
+    harvest_profile(ctx);
+    return ICPMI_OK;
+}
+
+int icpmi_comm_unique_id(icpmi_ctx *ctx, void *id_out)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!id_out) return fail(ctx, ICPMI_ERR_NULL, "id_out is NULL");
+    if ((rc = load_rccl(ctx))) return rc;
+    static_assert(sizeof(ncclUniqueId) == ICPMI_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    RCCL_TRY(ctx, ctx->rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return ICPMI_OK;
+}
+
+int icpmi_comm_init(icpmi_ctx *ctx, int32_t n_ranks, int32_t rank, const void *id)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ctx, ICPMI_ERR_ARG, "bad rank %d of %d", rank, n_ranks);
+    if (ctx->comm) return fail(ctx, ICPMI_ERR_ARG, "communicator already initialised");
+    if (n_ranks == 1) {
+        ctx->n_ranks = 1;
+        ctx->rank = 0;
+        return ICPMI_OK;
+    }
+    if (!id) return fail(ctx, ICPMI_ERR_NULL, "id is NULL");
+    if ((rc = load_rccl(ctx))) return rc;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    RCCL_TRY(ctx, ctx->rccl.CommInitRank(&ctx->comm, n_ranks, uid, rank));
+    ctx->n_ranks = n_ranks;
+    ctx->rank = rank;
+    return ICPMI_OK;
+}
+
+int icpmi_comm_finalize(icpmi_ctx *ctx)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (ctx->comm) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        RCCL_TRY(ctx, ctx->rccl.CommDestroy(ctx->comm));
+        ctx->comm = nullptr;
+    }
+    ctx->n_ranks = 1;
+    ctx->rank = 0;
+    return ICPMI_OK;
+}
+
+int icpmi_reset_profile(icpmi_ctx *ctx)
+{
+    if (!ctx) return ICPMI_ERR_NULL;
+    memset(&ctx->prof, 0, sizeof(ctx->prof));
+    return ICPMI_OK;
+}
+
+int icpmi_get_profile(icpmi_ctx *ctx, icpmi_profile *out)
+{
+    if (!ctx || !out) return ICPMI_ERR_NULL;
+    *out = ctx->prof;
+    return ICPMI_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,400 @@
+// kernels.h -- HIP kernels of the point-to-plane ICP path for gfx950 (wave64).
+//
+//   k_nn_f64          exact fp64 exhaustive nearest neighbour (kdtree.hpp:43-59,112-142)
+//   k_nn_merge        min over target splits
+//   k_knn_normals     exact k-NN + PCA normal per target point (icp.hpp:23-67)
+//   k_reduce          residuals + 6x6 normal-equation partial sums (icp.hpp:99-120,198-206)
+//   k_finish / k_step fixed-order final sum, error, convergence test, LDLT solve,
+//                     Rodrigues, pose accumulation (icp.hpp:207-231)
+//   k_transform       cloud * R^T + t^T (icp.hpp:174-176,225-226)
+//
+// All arithmetic that decides an index or a flag is fp64 in the reference's operation
+// order (no FMA contraction in this TU).  Reductions use wave shuffles + LDS and a fixed
+// partial order: results are run-to-run bit-stable (no float atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+
+namespace icpmi {
+
+constexpr int kWave = 64;
+constexpr int kNumSums = 29;       // 21 JtJ (upper, row by row) + 6 Jtb + sum b^2 + count
+constexpr int kSumsStride = 32;
+
+struct IcpState {
+    double total[16];       // accumulated source->target transform (icp.hpp:178,229)
+    double delta[16];       // last update (icp.hpp:220)
+    double sums[kSumsStride];
+    double prev_error;      // icp.hpp:179,231
+    double last_error;
+    double final_error;
+    double tolerance;
+    double min_error;
+    int32_t hist_len;
+    int32_t done;           // loop left (break or exhausted): later kernels are no-ops
+    int32_t converged;
+    int32_t loops;
+    int32_t max_hist;
+    int32_t pad;
+};
+
+// ------------------------------------------------------------------------------------
+// exact fp64 exhaustive 1-NN.  grid = (query blocks, target splits), 256 threads, QPT
+// queries per thread held in registers.  Every lane needs the same target point at the
+// same time, so targets come through the scalar unit (wave-uniform address -> s_load into
+// SGPRs, broadcast to the VALU for free) instead of LDS.
+// ------------------------------------------------------------------------------------
+template <int QPT>
+__global__ __launch_bounds__(256) void k_nn_f64(const double *__restrict__ qry, int n,
+                                                const double *__restrict__ tgt, int m,
+                                                int tgt_per_split,
+                                                double *__restrict__ out_d2,
+                                                int *__restrict__ out_idx,
+                                                const IcpState *__restrict__ st)
+{
+    if (st && st->done) return;
+    const int base = blockIdx.x * (256 * QPT) + threadIdx.x;
+    double px[QPT], py[QPT], pz[QPT], best[QPT];
+    int bidx[QPT];
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        const int i = base + r * 256;
+        const int ic = i < n ? i : n - 1;
+        px[r] = qry[3 * ic];
+        py[r] = qry[3 * ic + 1];
+        pz[r] = qry[3 * ic + 2];
+        best[r] = 1.7976931348623157e308; // DBL_MAX, kdtree.hpp:54
+        bidx[r] = -1;
+    }
+    const int j0 = blockIdx.y * tgt_per_split;
+    const int j1 = min(m, j0 + tgt_per_split);
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const double tx = tgt[3 * j], ty = tgt[3 * j + 1], tz = tgt[3 * j + 2];
+#pragma unroll
+        for (int r = 0; r < QPT; ++r) {
+            const double d = sqdist(tx, ty, tz, px[r], py[r], pz[r]);
+            if (d < best[r]) { // strict: first (lowest-index) minimum wins
+                best[r] = d;
+                bidx[r] = j;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        const int i = base + r * 256;
+        if (i < n) {
+            out_d2[(size_t)blockIdx.y * n + i] = best[r];
+            out_idx[(size_t)blockIdx.y * n + i] = bidx[r];
+        }
+    }
+}
+
+// min over splits; ties -> lowest index (splits are in increasing index order)
+__global__ __launch_bounds__(256) void k_nn_merge(const double *__restrict__ part_d2,
+                                                  const int *__restrict__ part_idx, int n,
+                                                  int splits, int *__restrict__ idx,
+                                                  double *__restrict__ d2,
+                                                  const IcpState *__restrict__ st)
+{
+    if (st && st->done) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double best = part_d2[i];
+    int bi = part_idx[i];
+    for (int s = 1; s < splits; ++s) {
+        const double d = part_d2[(size_t)s * n + i];
+        if (d < best) {
+            best = d;
+            bi = part_idx[(size_t)s * n + i];
+        }
+    }
+    idx[i] = bi;
+    if (d2) d2[i] = best;
+}
+
+// ------------------------------------------------------------------------------------
+// exact k-NN + PCA normal, one target point per thread.  The k-entry list, sorted
+// ascending by (distance, index), lives in LDS as [slot][thread]; the k-th distance is
+// kept in a register as the acceptance threshold, so the common path is 8 fp64 ops and a
+// compare per pair.
+// ------------------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_knn_normals(const double *__restrict__ pts, int m, int k,
+                                                       int row0, int row1,
+                                                       double *__restrict__ normals)
+{
+    extern __shared__ double knn_smem[];
+    double *ld = knn_smem;
+    int *li = reinterpret_cast<int *>(knn_smem + (size_t)k * BLOCK);
+    const int tid = threadIdx.x;
+    const int i = row0 + blockIdx.x * BLOCK + tid;
+    const bool active = i < row1;
+    const int ic = active ? i : row0;
+    const double px = pts[3 * ic], py = pts[3 * ic + 1], pz = pts[3 * ic + 2];
+    int cnt = active ? 0 : k;
+    double thr = active ? __builtin_inf() : -1.0;
+
+#pragma unroll 4
+    for (int j = 0; j < m; ++j) {
+        const double tx = pts[3 * j], ty = pts[3 * j + 1], tz = pts[3 * j + 2];
+        const double d = sqdist(tx, ty, tz, px, py, pz);
+        if (d < thr) {
+            int pos = cnt < k ? cnt : k - 1;
+            while (pos > 0) {
+                const double prev = ld[(pos - 1) * BLOCK + tid];
+                if (!(prev > d)) break;
+                ld[pos * BLOCK + tid] = prev;
+                li[pos * BLOCK + tid] = li[(pos - 1) * BLOCK + tid];
+                --pos;
+            }
+            ld[pos * BLOCK + tid] = d;
+            li[pos * BLOCK + tid] = j;
+            if (cnt < k) ++cnt;
+            if (cnt == k) thr = ld[(k - 1) * BLOCK + tid];
+        }
+    }
+    if (!active) return;
+
+    double nx = 0.0, ny = 0.0, nz = 1.0; // icp.hpp:34-37
+    if (cnt >= 3) {
+        double cx = 0.0, cy = 0.0, cz = 0.0; // icp.hpp:40-44
+        for (int a = 0; a < cnt; ++a) {
+            const int j = li[a * BLOCK + tid];
+            cx += pts[3 * j];
+            cy += pts[3 * j + 1];
+            cz += pts[3 * j + 2];
+        }
+        const double kd = (double)cnt;
+        cx /= kd;
+        cy /= kd;
+        cz /= kd;
+        double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0; // icp.hpp:47-52
+        for (int a = 0; a < cnt; ++a) {
+            const int j = li[a * BLOCK + tid];
+            const double dx = pts[3 * j] - cx, dy = pts[3 * j + 1] - cy, dz = pts[3 * j + 2] - cz;
+            c00 += dx * dx;
+            c01 += dx * dy;
+            c02 += dx * dz;
+            c11 += dy * dy;
+            c12 += dy * dz;
+            c22 += dz * dz;
+        }
+        const double cov[6] = {c00 / kd, c01 / kd, c02 / kd, c11 / kd, c12 / kd, c22 / kd};
+        double v[3];
+        smallest_eigvec_sym3(cov, v); // icp.hpp:55-56
+        if (v[2] < 0.0) {             // icp.hpp:59-61
+            v[0] = -v[0];
+            v[1] = -v[1];
+            v[2] = -v[2];
+        }
+        const double z = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]; // icp.hpp:63
+        if (z > 0.0) {
+            const double s = __dsqrt_rn(z);
+            v[0] /= s;
+            v[1] /= s;
+            v[2] /= s;
+        }
+        nx = v[0];
+        ny = v[1];
+        nz = v[2];
+    }
+    normals[3 * i] = nx;
+    normals[3 * i + 1] = ny;
+    normals[3 * i + 2] = nz;
+}
+
+// ------------------------------------------------------------------------------------
+// residuals + normal equations.  Each thread accumulates the 28 sums over a grid-stride
+// slice, then wave shuffle reduction -> LDS across the 4 waves -> one partial row per
+// block.  HBM-bound gather: 24 B (p) + 4 B (idx) + 24 B (q) + 24 B (n) per point.
+// When `matched` is non-null, q and n come from row i of (tgt, nrm) (icp.hpp:89-93).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ cur, int n,
+                                                const double *__restrict__ tgt,
+                                                const double *__restrict__ nrm,
+                                                const int *__restrict__ idx,
+                                                double *__restrict__ partials,
+                                                const IcpState *__restrict__ st)
+{
+    if (st && st->done) return;
+    double acc[28];
+#pragma unroll
+    for (int e = 0; e < 28; ++e) acc[e] = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int j = idx ? idx[i] : i;
+        const double p0 = cur[3 * i], p1 = cur[3 * i + 1], p2 = cur[3 * i + 2];
+        const double q0 = tgt[3 * j], q1 = tgt[3 * j + 1], q2 = tgt[3 * j + 2];
+        const double n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
+        double J[6];
+        J[0] = p1 * n2 - p2 * n1; // p x n, icp.hpp:105
+        J[1] = p2 * n0 - p0 * n2;
+        J[2] = p0 * n1 - p1 * n0;
+        J[3] = n0;
+        J[4] = n1;
+        J[5] = n2;
+        const double d0 = q0 - p0, d1 = q1 - p1, d2 = q2 - p2;
+        const double b = (d0 * n0 + d1 * n1) + d2 * n2; // icp.hpp:116
+        int o = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) acc[o++] += J[r] * J[c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[21 + r] += J[r] * b;
+        acc[27] += b * b;
+    }
+    __shared__ double red[4][28];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < 28; ++e) {
+        const double s = wave_sum(acc[e]);
+        if (lane == 0) red[wave][e] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 28) {
+        const int e = threadIdx.x;
+        partials[(size_t)blockIdx.x * kSumsStride + e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    }
+}
+
+// sum the per-block partial rows in a fixed order -> st->sums[0..27]; sums[28] = count
+__device__ inline void finish_sums(const double *__restrict__ partials, int nblocks, int n_local,
+                                   IcpState *st)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6; // 256 threads
+    for (int e = wave; e < 28; e += 4) {
+        double s = 0.0;
+        for (int b = lane; b < nblocks; b += kWave) s += partials[(size_t)b * kSumsStride + e];
+        s = wave_sum(s);
+        if (lane == 0) st->sums[e] = s;
+    }
+    if (threadIdx.x == 0) st->sums[28] = (double)n_local;
+}
+
+// error, convergence tests, solve, accumulate (icp.hpp:206-231 / 251-255)
+__device__ inline void step_update(IcpState *st, double *history, int final_pass)
+{
+    if (st->done) {
+        if (final_pass) {
+            // the loop broke on convergence: the source has not moved since the last
+            // evaluation, so the reference's post-loop pass (icp.hpp:235-252) recomputes
+            // exactly last_error
+            st->final_error = st->last_error;
+            if (st->hist_len < st->max_hist) history[st->hist_len] = st->last_error;
+            st->hist_len += 1;
+        }
+        return;
+    }
+    const double error = __dsqrt_rn(st->sums[27] / st->sums[28]);
+    if (st->hist_len < st->max_hist) history[st->hist_len] = error;
+    st->hist_len += 1;
+    st->last_error = error;
+    if (final_pass) {
+        st->final_error = error;
+        st->done = 1;
+        return;
+    }
+    st->loops += 1;
+    if (error < st->min_error) { // icp.hpp:210-213
+        st->converged = 1;
+        st->done = 1;
+        return;
+    }
+    if (fabs(st->prev_error - error) < st->tolerance) { // icp.hpp:214-217
+        st->converged = 1;
+        st->done = 1;
+        return;
+    }
+    double M[36], rhs[6], x[6];
+    int o = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) {
+            M[r * 6 + c] = st->sums[o];
+            M[c * 6 + r] = st->sums[o];
+            ++o;
+        }
+    for (int r = 0; r < 6; ++r) rhs[r] = st->sums[21 + r];
+    ldlt6_solve(M, rhs, x);              // icp.hpp:120
+    twist_to_transform(x, st->delta);    // icp.hpp:123-143
+    mul44(st->delta, st->total, st->total); // icp.hpp:229
+    st->prev_error = error;              // icp.hpp:231
+}
+
+// single GPU: final sum + step in one launch
+__global__ __launch_bounds__(256) void k_finish_step(const double *__restrict__ partials,
+                                                     int nblocks, int n_local, IcpState *st,
+                                                     double *history, int final_pass)
+{
+    if (!st->done) finish_sums(partials, nblocks, n_local, st);
+    __syncthreads();
+    if (threadIdx.x == 0) step_update(st, history, final_pass);
+}
+
+// multi GPU: k_finish -> ncclAllReduce(st->sums, 29) -> k_step
+__global__ __launch_bounds__(256) void k_finish(const double *__restrict__ partials, int nblocks,
+                                                int n_local, IcpState *st)
+{
+    if (st->done) {
+        // keep the all-reduce operands finite and identical on every rank
+        if (threadIdx.x < kNumSums) st->sums[threadIdx.x] = 0.0;
+        return;
+    }
+    finish_sums(partials, nblocks, n_local, st);
+}
+
+__global__ void k_step(IcpState *st, double *history, int final_pass)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) step_update(st, history, final_pass);
+}
+
+// one-shot solve for icpmi_solve_point_to_plane (icp.hpp:89-144)
+__global__ __launch_bounds__(256) void k_finish_solve(const double *__restrict__ partials,
+                                                      int nblocks, int n_local, IcpState *st)
+{
+    finish_sums(partials, nblocks, n_local, st);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double M[36], rhs[6], x[6];
+        int o = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) {
+                M[r * 6 + c] = st->sums[o];
+                M[c * 6 + r] = st->sums[o];
+                ++o;
+            }
+        for (int r = 0; r < 6; ++r) rhs[r] = st->sums[21 + r];
+        ldlt6_solve(M, rhs, x);
+        twist_to_transform(x, st->delta);
+    }
+}
+
+// out = in * R^T + t^T with T read from device memory (st->delta or a staged matrix).
+// which: 0 = st->delta, 1 = st->total
+__global__ __launch_bounds__(256) void k_transform(const double *in, double *out, int n,
+                                                   const IcpState *__restrict__ st, int which,
+                                                   int honour_done)
+{
+    if (honour_done && st->done) return;
+    const double *T = which ? st->total : st->delta;
+    const double r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3];
+    const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
+    const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        out[3 * i] = ((x * r00 + y * r01) + z * r02) + t0;
+        out[3 * i + 1] = ((x * r10 + y * r11) + z * r12) + t1;
+        out[3 * i + 2] = ((x * r20 + y * r21) + z * r22) + t2;
+    }
+}
+
+} // namespace icpmi

@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as orc
+    orc.build()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """One context for the whole GPU session.  Fails loudly (no skip, no fallback) when
+    the HIP library or the device is missing."""
+    from lidar_slam_from_scratch_amd import build, capi
+    build.build_library()
+    ctx = capi.Context(device=0, profile=True)
+    yield ctx
+    ctx.close()
