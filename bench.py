@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- ICP iterations/sec on the 100k -> 100k synthetic scan (BASELINE.json configs[2]).
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one ICP iteration (icp.hpp:181-232: correspondence search, residual + 6x6
+normal-equation reduction, solve, transform).  The timed region is ONE icpmi_align_device
+call with max_iterations = K, tolerance = min_error = 0 (so exactly K iterations run,
+icp.hpp:210,214 cannot fire), inputs already resident in HBM.  It therefore also contains
+what the reference pays on every call: normal estimation of the target (icp.hpp:169-171)
+and the post-loop evaluation pass (icp.hpp:235-252); `value` = K / that time.  The
+loop-only rate is reported beside it as `steady_state_it_per_s`.
+
+With N > 1 ranks the source cloud is sharded N ways (strong scaling of the same 100k ->
+100k job); the 29-double all-reduce per iteration runs over RCCL inside the library.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector = FP32 MFMA (v_mfma_f32_16x16x4_f32)
+FLOP_PER_PAIR = 8.0        # 3 sub + 1 mul + 2 fma
+
+
+def cpu_baseline(src, tgt, steps):
+    """The oracle (CPU restatement of the reference: kd-tree, two NN passes per iteration,
+    single thread like the reference) on the same workload.  Timed as the checker's
+    baseline only -- never part of the measured GPU path."""
+    from oracle import oracle as orc
+    t0 = time.time()
+    r = orc.icp_point_to_plane(src, tgt, max_iterations=steps, tolerance=0.0, min_error=0.0,
+                               faithful=True, nthreads=1)
+    wall = time.time() - t0
+    loops = max(r.loop_iterations, 1)
+    return {
+        "value": loops / wall, "unit": "ICP iterations/s", "cores": 1, "kind": "port",
+        "sample": "same C3 100k->100k pair, one full call of %d iterations (kd-tree build + "
+                  "20-NN normals + loop + final pass), 1 thread" % loops,
+        "steady_state_it_per_s": loops / r.loop_seconds,
+        "setup_s": r.setup_seconds, "loop_s": r.loop_seconds, "final_s": r.final_seconds,
+        "result": r,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=100_000)
+    ap.add_argument("--search", type=int, default=0, help="0 auto, 1 exact fp64, 2 mfma fp32 + recheck")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=None)
+    args = ap.parse_args()
+
+    import torch
+    from lidar_slam_from_scratch_amd import capi, dist as icpdist, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    src, tgt, _T = synth.c3_uniform(args.points)
+    lo, hi = icpdist.shard_bounds(src.shape[0], world, rank)
+    d_src = torch.from_numpy(np.ascontiguousarray(src[lo:hi])).to(dev)
+    d_tgt = torch.from_numpy(tgt).to(dev)
+    torch.cuda.synchronize()
+
+    ctx = capi.Context(device=local_rank, search=args.search, profile=True)
+    if world > 1:
+        icpdist.init_rccl(ctx, dist, device=dev)
+
+    def call(iters):
+        cfg = capi.Context.make_config(max_iterations=iters, tolerance=0.0, min_error=0.0)
+        return ctx.align_device(d_src.data_ptr(), hi - lo, d_tgt.data_ptr(), tgt.shape[0], cfg)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        call(args.warmup)
+    ctx.reset_profile()
+    fence()
+    t0 = time.perf_counter()
+    res, hist = call(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = ctx.get_profile()
+    assert res.loop_iterations == args.steps, (res.loop_iterations, args.steps)
+
+    if rank == 0:
+        n_local, m = hi - lo, tgt.shape[0]
+        nn_avg_ms = prof["nn_ms"] / max(prof["nn_launches"], 1)
+        flops = FLOP_PER_PAIR * n_local * m
+        achieved = flops / (nn_avg_ms * 1e-3) / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "nn_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "ICP iterations/sec (100k->100k pts)",
+            "value": args.steps / elapsed,
+            "unit": "ICP iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C3: synthetic %d->%d-pt uniform random scan, %d ICP iterations, "
+                                   "1 call incl. 20-NN normals + final pass" % (src.shape[0], m, args.steps),
+                       "source_points": int(src.shape[0]), "target_points": int(m),
+                       "parallelism": "source sharded x%d, 29-double RCCL all-reduce/iter" % world
+                       if world > 1 else "single GPU",
+                       "search": {0: "auto", 1: "exact_f64", 2: "mfma_f32+f64 recheck"}[args.search]},
+            "steady_state_it_per_s": args.steps / (prof["loop_ms"] * 1e-3) * (args.steps + 1) / args.steps
+            if prof["loop_ms"] > 0 else None,
+            "stage_ms": {k: prof[k] for k in ("nn_ms", "reduce_ms", "transform_ms", "normals_ms",
+                                              "loop_ms", "total_ms")},
+            "final_error": res.final_error,
+            "roofline": {
+                "kernel": "correspondence search (nn pass)",
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                "flop_per_launch": flops, "avg_launch_ms": nn_avg_ms,
+                "algorithmic_bytes_per_launch": 24 * n_local + 24 * m + 4 * n_local,
+                "achieved_hbm_GBps": (24 * n_local + 24 * m + 4 * n_local) / (nn_avg_ms * 1e-3) / 1e9,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb = cpu_baseline(src, tgt, args.cpu_steps or args.steps)
+            r = cb.pop("result")
+            T = np.array(res.transformation[:]).reshape(4, 4)
+            if r.loop_iterations == args.steps:
+                dt, dr = synth.pose_delta(T, r.transformation)
+                out["parity"] = {"pose_dt_m": dt, "pose_dr_rad": dr,
+                                 "num_iterations_equal": bool(r.num_iterations == res.num_iterations),
+                                 "final_error_abs_diff": abs(r.final_error - res.final_error)}
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_1thread"] = out["value"] / cb["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

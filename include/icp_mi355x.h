@@ -79,6 +79,8 @@ typedef struct {
     double reduce_ms;    int64_t reduce_launches;    /* residual + 6x6 accumulation + solve */
     double transform_ms; int64_t transform_launches;
     double normals_ms;   int64_t normals_launches;   /* k-NN + PCA */
+    double total_ms;     int64_t calls;              /* whole icpmi_align* calls, device time */
+    double loop_ms;                                  /* iteration loop + post-loop pass only */
     double nn_pairs;                                 /* (source,target) pairs evaluated by nn passes */
     int64_t nn_recheck_queries;                      /* queries re-resolved in fp64 (MFMA engine) */
     int64_t nn_fallback_queries;                     /* queries sent to the fp64 exhaustive fallback */
@@ -133,6 +135,15 @@ int icpmi_transform_points(icpmi_ctx *ctx, const double transform[16], const dou
 int icpmi_comm_unique_id(icpmi_ctx *ctx, void *id_out /* ICPMI_UNIQUE_ID_BYTES */);
 int icpmi_comm_init(icpmi_ctx *ctx, int32_t n_ranks, int32_t rank, const void *id);
 int icpmi_comm_finalize(icpmi_ctx *ctx);
+
+/* Same sharded path with the two exchanges done by host callbacks instead of RCCL (the
+ * buffers are host memory; the callee must leave the result in place).  Meant for
+ * rehearsing the N > 1 path where RCCL cannot run (several ranks on one GPU, gloo). */
+typedef int (*icpmi_allreduce_fn)(void *user, double *buf, int32_t count);            /* in-place sum */
+typedef int (*icpmi_allgather_fn)(void *user, double *buf, int32_t count_per_rank);   /* in-place, rank-major */
+int icpmi_comm_init_callbacks(icpmi_ctx *ctx, int32_t n_ranks, int32_t rank,
+                              icpmi_allreduce_fn allreduce, icpmi_allgather_fn allgather,
+                              void *user);
 
 /* profiling */
 int icpmi_reset_profile(icpmi_ctx *ctx);

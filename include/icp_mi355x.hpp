@@ -1,0 +1,233 @@
+// icp_mi355x.hpp -- header-only C++17 host mirror of the reference's registration API on
+// top of the C ABI (icp_mi355x.h).  Eigen-free: the reference's types are restated with
+// plain storage so a caller without Eigen can use the same names and call shapes:
+//
+//   reference (slam_viz/include/slam_viz/core/)          here (namespace icp_mi355x)
+//   slam::PointCloud            types.hpp:15-61          PointCloud   (row-major N x 3 fp64)
+//   slam::Transformation        types.hpp:74-136         Transformation (row-major 4x4)
+//   slam::ICPConfig             types.hpp:143-148        ICPConfig
+//   slam::ICPResult             types.hpp:155-164        ICPResult
+//   slam::icp_point_to_plane    icp.hpp:157-161          icp_point_to_plane
+//   (north_star wording)                                 ICP::align
+//
+// A caller that already has Eigen and the reference's own types uses
+// slam_icp_adapter.hpp instead, which keeps slam::icp_point_to_plane's exact signature.
+#pragma once
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "icp_mi355x.h"
+
+namespace icp_mi355x {
+
+class PointCloud { // types.hpp:15-61
+public:
+    PointCloud() = default;
+    explicit PointCloud(std::vector<double> xyz) : xyz_(std::move(xyz))
+    {
+        if (xyz_.size() % 3) throw std::invalid_argument("PointCloud: size not a multiple of 3");
+    }
+    PointCloud(const double *xyz, std::size_t n) : xyz_(xyz, xyz + 3 * n) {}
+    const double *data() const { return xyz_.data(); }
+    double *data() { return xyz_.data(); }
+    std::size_t size() const { return xyz_.size() / 3; }
+    bool empty() const { return xyz_.empty(); }
+    const double *row(std::size_t i) const { return &xyz_[3 * i]; }
+    std::array<double, 3> centroid() const
+    {
+        std::array<double, 3> c{0, 0, 0};
+        for (std::size_t i = 0; i < size(); ++i)
+            for (int a = 0; a < 3; ++a) c[a] += xyz_[3 * i + a];
+        if (size())
+            for (int a = 0; a < 3; ++a) c[a] /= static_cast<double>(size());
+        return c;
+    }
+    PointCloud copy() const { return PointCloud(xyz_); }
+
+private:
+    std::vector<double> xyz_;
+};
+
+class Transformation { // types.hpp:74-136, row-major storage
+public:
+    Transformation() { m_ = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; }
+    explicit Transformation(const std::array<double, 16> &row_major) : m_(row_major) {}
+    static Transformation identity() { return Transformation(); }
+    static Transformation from_rt(const std::array<double, 9> &R, const std::array<double, 3> &t)
+    {
+        Transformation T;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) T.m_[4 * i + j] = R[3 * i + j];
+            T.m_[4 * i + 3] = t[i];
+        }
+        return T;
+    }
+    const std::array<double, 16> &matrix() const { return m_; }
+    double operator()(int r, int c) const { return m_[4 * r + c]; }
+    std::array<double, 3> t() const { return {m_[3], m_[7], m_[11]}; }
+    std::array<double, 3> apply(const std::array<double, 3> &p) const
+    {
+        std::array<double, 3> o;
+        for (int r = 0; r < 3; ++r)
+            o[r] = ((p[0] * m_[4 * r] + p[1] * m_[4 * r + 1]) + p[2] * m_[4 * r + 2]) + m_[4 * r + 3];
+        return o;
+    }
+    PointCloud apply(const PointCloud &cloud) const // cloud * R^T + t^T, types.hpp:110-115
+    {
+        std::vector<double> out(3 * cloud.size());
+        for (std::size_t i = 0; i < cloud.size(); ++i) {
+            const double *p = cloud.row(i);
+            auto o = apply({p[0], p[1], p[2]});
+            out[3 * i] = o[0];
+            out[3 * i + 1] = o[1];
+            out[3 * i + 2] = o[2];
+        }
+        return PointCloud(std::move(out));
+    }
+    Transformation compose(const Transformation &other) const // this applied after other
+    {
+        std::array<double, 16> c{};
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double s = 0;
+                for (int k = 0; k < 4; ++k) s += m_[4 * i + k] * other.m_[4 * k + j];
+                c[4 * i + j] = s;
+            }
+        return Transformation(c);
+    }
+    Transformation operator*(const Transformation &other) const { return compose(other); }
+    Transformation inverse() const // (R^T, -R^T t), types.hpp:128-132
+    {
+        std::array<double, 9> Rt;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Rt[3 * i + j] = m_[4 * j + i];
+        std::array<double, 3> ti;
+        for (int i = 0; i < 3; ++i) ti[i] = -(Rt[3 * i] * m_[3] + Rt[3 * i + 1] * m_[7] + Rt[3 * i + 2] * m_[11]);
+        return from_rt(Rt, ti);
+    }
+
+private:
+    std::array<double, 16> m_;
+};
+
+struct ICPConfig { // types.hpp:143-148
+    int max_iterations = 50;
+    double tolerance = 1e-6;
+    double min_error = 1e-9;
+    Transformation initial_transform = Transformation::identity();
+};
+
+struct ICPResult { // types.hpp:155-164
+    Transformation transformation;
+    bool converged = false;
+    int num_iterations = 0;
+    std::vector<double> error_history;
+    double final_error = 0.0;
+    bool success() const { return converged && final_error < 0.1; }
+};
+
+class IcpError : public std::runtime_error {
+public:
+    IcpError(int code, const std::string &what) : std::runtime_error(what), code_(code) {}
+    int code() const { return code_; }
+
+private:
+    int code_;
+};
+
+// RAII owner of an icpmi_ctx (device buffers, stream, optional RCCL communicator).
+class Context {
+public:
+    explicit Context(int device = 0, int normal_k = 20, int search = ICPMI_SEARCH_AUTO)
+    {
+        icpmi_options o;
+        icpmi_options_default(&o);
+        o.device = device;
+        o.normal_k = normal_k;
+        o.search = search;
+        int rc = icpmi_create(&o, &ctx_);
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(nullptr));
+    }
+    ~Context() { icpmi_destroy(ctx_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    icpmi_ctx *get() const { return ctx_; }
+
+private:
+    icpmi_ctx *ctx_ = nullptr;
+};
+
+// One context per thread, created on first use (the reference's function is stateless;
+// the context only caches device allocations between calls).
+inline Context &default_context()
+{
+    thread_local Context ctx;
+    return ctx;
+}
+
+namespace detail {
+inline icpmi_config to_c(const ICPConfig &c)
+{
+    icpmi_config k;
+    icpmi_config_default(&k);
+    k.max_iterations = c.max_iterations;
+    k.tolerance = c.tolerance;
+    k.min_error = c.min_error;
+    for (int i = 0; i < 16; ++i) k.initial_transform[i] = c.initial_transform.matrix()[i];
+    return k;
+}
+} // namespace detail
+
+// Raw-pointer form: row-major N x 3 fp64 clouds (what PointCloud::points().data() is in
+// the reference, types.hpp:17).
+inline ICPResult icp_point_to_plane(Context &ctx, const double *source_xyz, std::size_t n_src,
+                                    const double *target_xyz, std::size_t n_tgt,
+                                    const ICPConfig &config = ICPConfig())
+{
+    icpmi_config k = detail::to_c(config);
+    std::vector<double> hist(static_cast<std::size_t>(config.max_iterations > 0 ? config.max_iterations : 0) + 1);
+    icpmi_result r;
+    int rc = icpmi_align(ctx.get(), source_xyz, static_cast<int64_t>(n_src), target_xyz,
+                         static_cast<int64_t>(n_tgt), &k, &r, hist.data(), static_cast<int32_t>(hist.size()));
+    if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx.get()));
+    ICPResult out;
+    std::array<double, 16> m;
+    for (int i = 0; i < 16; ++i) m[i] = r.transformation[i];
+    out.transformation = Transformation(m);
+    out.converged = r.converged != 0;
+    out.num_iterations = r.num_iterations;
+    out.final_error = r.final_error;
+    hist.resize(static_cast<std::size_t>(r.history_len));
+    out.error_history = std::move(hist);
+    return out;
+}
+
+// Same call shape as slam::icp_point_to_plane (icp.hpp:157-161).
+inline ICPResult icp_point_to_plane(const PointCloud &source, const PointCloud &target,
+                                    const ICPConfig &config = ICPConfig())
+{
+    return icp_point_to_plane(default_context(), source.data(), source.size(), target.data(),
+                              target.size(), config);
+}
+
+// `ICP(config).align(source, target)`: the facade BASELINE.json's north_star names.
+class ICP {
+public:
+    explicit ICP(ICPConfig config = ICPConfig()) : config_(std::move(config)) {}
+    ICPResult align(const PointCloud &source, const PointCloud &target) const
+    {
+        return icp_point_to_plane(source, target, config_);
+    }
+    ICPConfig &config() { return config_; }
+
+private:
+    ICPConfig config_;
+};
+
+} // namespace icp_mi355x

@@ -1,0 +1,91 @@
+// slam_icp_adapter.hpp -- drop-in for a caller that HAS Eigen and the reference's own
+// types (slam::PointCloud / Transformation / ICPConfig / ICPResult, core/types.hpp).
+//
+// Include this INSTEAD of "slam_viz/core/icp.hpp" (it includes types.hpp itself); the two
+// call sites, slam_node.cpp:138 and loop_closure.hpp:109, stay as they are:
+//
+//     auto result = slam::icp_point_to_plane(source, target, icp_cfg);
+//
+// Differences from the reference implementation, by design:
+//   - any error from the library (empty cloud, HIP failure) yields
+//     ICPResult{converged = false}, so slam_node.cpp:139's gate falls back to identity
+//     instead of the reference's undefined behaviour on empty input;
+//   - Eigen::Matrix4d is column-major, the C ABI is row-major: converted element-wise.
+//
+// This header cannot be compiled in the authoring image (no Eigen); it is kept free of
+// anything but the reference's public accessors: points().data(), points().rows(),
+// matrix()(r,c), Transformation(Matrix4).
+#pragma once
+
+#include <vector>
+
+#include "slam_viz/core/types.hpp"
+
+#include "icp_mi355x.h"
+
+namespace slam {
+
+namespace icp_mi355x_detail {
+inline icpmi_ctx *context()
+{
+    struct Holder {
+        icpmi_ctx *ctx = nullptr;
+        Holder()
+        {
+            icpmi_options o;
+            icpmi_options_default(&o);
+            if (icpmi_create(&o, &ctx) != ICPMI_OK) ctx = nullptr;
+        }
+        ~Holder() { icpmi_destroy(ctx); }
+    };
+    thread_local Holder h;
+    return h.ctx;
+}
+} // namespace icp_mi355x_detail
+
+// Same signature as core/icp.hpp:157-161.
+inline ICPResult icp_point_to_plane(const PointCloud &source, const PointCloud &target,
+                                    const ICPConfig &config = ICPConfig())
+{
+    ICPResult result; // converged = false, identity transform (types.hpp:155-160)
+    icpmi_ctx *ctx = icp_mi355x_detail::context();
+    if (!ctx) return result;
+
+    icpmi_config k;
+    icpmi_config_default(&k);
+    k.max_iterations = config.max_iterations;
+    k.tolerance = config.tolerance;
+    k.min_error = config.min_error;
+    const auto &M0 = config.initial_transform.matrix();
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) k.initial_transform[4 * r + c] = M0(r, c);
+
+    std::vector<double> hist(static_cast<size_t>(config.max_iterations > 0 ? config.max_iterations : 0) + 1);
+    icpmi_result out;
+    // PointCloud::Matrix is Eigen row-major N x 3 (types.hpp:17): data() is xyzxyz...
+    const int rc = icpmi_align(ctx, source.points().data(), static_cast<int64_t>(source.points().rows()),
+                               target.points().data(), static_cast<int64_t>(target.points().rows()), &k,
+                               &out, hist.data(), static_cast<int32_t>(hist.size()));
+    if (rc != ICPMI_OK) return result;
+
+    Transformation::Matrix4 M;
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) M(r, c) = out.transformation[4 * r + c];
+    result.transformation = Transformation(M);
+    result.converged = out.converged != 0;
+    result.num_iterations = out.num_iterations;
+    result.final_error = out.final_error;
+    result.error_history.assign(hist.begin(), hist.begin() + out.history_len);
+    return result;
+}
+
+// The facade named in BASELINE.json's north_star.
+struct ICP {
+    ICPConfig config;
+    ICPResult align(const PointCloud &source, const PointCloud &target) const
+    {
+        return icp_point_to_plane(source, target, config);
+    }
+};
+
+} // namespace slam

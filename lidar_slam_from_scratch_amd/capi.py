@@ -21,6 +21,7 @@ EXPORTS = [
     "icpmi_destroy", "icpmi_last_error", "icpmi_align", "icpmi_align_device",
     "icpmi_nearest_batch", "icpmi_estimate_normals", "icpmi_solve_point_to_plane",
     "icpmi_transform_points", "icpmi_comm_unique_id", "icpmi_comm_init", "icpmi_comm_finalize",
+    "icpmi_comm_init_callbacks",
     "icpmi_reset_profile", "icpmi_get_profile",
 ]
 
@@ -47,8 +48,13 @@ class Profile(C.Structure):
                 ("reduce_ms", C.c_double), ("reduce_launches", C.c_int64),
                 ("transform_ms", C.c_double), ("transform_launches", C.c_int64),
                 ("normals_ms", C.c_double), ("normals_launches", C.c_int64),
+                ("total_ms", C.c_double), ("calls", C.c_int64), ("loop_ms", C.c_double),
                 ("nn_pairs", C.c_double), ("nn_recheck_queries", C.c_int64),
                 ("nn_fallback_queries", C.c_int64)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
 
 
 class IcpError(RuntimeError):
@@ -91,6 +97,7 @@ def load_library(path=None):
     L.icpmi_comm_unique_id.argtypes = [vp, vp]
     L.icpmi_comm_init.argtypes = [vp, C.c_int32, C.c_int32, vp]
     L.icpmi_comm_finalize.argtypes = [vp]
+    L.icpmi_comm_init_callbacks.argtypes = [vp, C.c_int32, C.c_int32, ALLREDUCE_FN, ALLGATHER_FN, vp]
     L.icpmi_reset_profile.argtypes = [vp]
     L.icpmi_get_profile.argtypes = [vp, C.POINTER(Profile)]
     for name in EXPORTS:
@@ -203,6 +210,31 @@ class Context:
     def comm_init(self, n_ranks, rank, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES) if unique_id else None
         self._check(self._lib.icpmi_comm_init(self._h, n_ranks, rank, buf))
+        self.n_ranks, self.rank = n_ranks, rank
+
+    def comm_init_callbacks(self, n_ranks, rank, allreduce, allgather):
+        """allreduce(np_array) / allgather(np_array, per_rank): in-place on a host numpy view."""
+        def _ar(_user, buf, count):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:  # noqa: BLE001 -- must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _ag(_user, buf, per):
+            try:
+                allgather(np.ctypeslib.as_array(buf, shape=(per * n_ranks,)), per)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = (ALLREDUCE_FN(_ar), ALLGATHER_FN(_ag))  # keep alive
+        self._check(self._lib.icpmi_comm_init_callbacks(self._h, n_ranks, rank, self._cb[0],
+                                                        self._cb[1], None))
         self.n_ranks, self.rank = n_ranks, rank
 
     def comm_finalize(self):

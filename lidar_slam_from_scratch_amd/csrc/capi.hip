@@ -38,7 +38,7 @@ struct EventPair {
     int stage;
 };
 
-enum Stage { ST_NN = 0, ST_REDUCE = 1, ST_TRANSFORM = 2, ST_NORMALS = 3, ST_COUNT = 4 };
+enum Stage { ST_NN = 0, ST_REDUCE = 1, ST_TRANSFORM = 2, ST_NORMALS = 3, ST_TOTAL = 4, ST_LOOP = 5 };
 
 struct Rccl {
     void *lib = nullptr;
@@ -73,6 +73,10 @@ struct icpmi_ctx {
     Rccl rccl;
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
+    icpmi_allreduce_fn cb_allreduce = nullptr;
+    icpmi_allgather_fn cb_allgather = nullptr;
+    void *cb_user = nullptr;
+    std::vector<double> cb_host;
 };
 
 namespace {
@@ -155,6 +159,8 @@ void harvest_profile(icpmi_ctx *ctx)
         case ST_REDUCE: ctx->prof.reduce_ms += ms; ctx->prof.reduce_launches++; break;
         case ST_TRANSFORM: ctx->prof.transform_ms += ms; ctx->prof.transform_launches++; break;
         case ST_NORMALS: ctx->prof.normals_ms += ms; ctx->prof.normals_launches++; break;
+        case ST_TOTAL: ctx->prof.total_ms += ms; ctx->prof.calls++; break;
+        case ST_LOOP: ctx->prof.loop_ms += ms; break;
         default: break;
         }
     }
@@ -245,6 +251,42 @@ int load_rccl(icpmi_ctx *ctx)
                         ctx->rccl.GetErrorString(r_));                                        \
     } while (0)
 
+// ---- exchanges of the sharded path --------------------------------------------------------
+// in-place sum of `count` doubles at device address d_buf over all ranks
+int exchange_allreduce(icpmi_ctx *ctx, double *d_buf, int count)
+{
+    if (ctx->comm) {
+        RCCL_TRY(ctx, ctx->rccl.AllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+        return ICPMI_OK;
+    }
+    ctx->cb_host.resize(std::max<size_t>(ctx->cb_host.size(), count));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->cb_host.data(), d_buf, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->cb_allreduce(ctx->cb_user, ctx->cb_host.data(), count) != 0)
+        return fail(ctx, ICPMI_ERR_RCCL, "all-reduce callback failed");
+    HIP_TRY(ctx, hipMemcpyAsync(d_buf, ctx->cb_host.data(), sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPMI_OK;
+}
+
+// in-place all-gather: rank r's `per` doubles sit at d_buf + r * per
+int exchange_allgather(icpmi_ctx *ctx, double *d_buf, size_t per)
+{
+    if (ctx->comm) {
+        RCCL_TRY(ctx, ctx->rccl.AllGather(d_buf + (size_t)ctx->rank * per, d_buf, per, ncclDouble, ctx->comm, ctx->stream));
+        return ICPMI_OK;
+    }
+    const size_t total = per * ctx->n_ranks;
+    ctx->cb_host.resize(std::max(ctx->cb_host.size(), total));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->cb_host.data(), d_buf, sizeof(double) * total, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->cb_allgather(ctx->cb_user, ctx->cb_host.data(), (int32_t)per) != 0)
+        return fail(ctx, ICPMI_ERR_RCCL, "all-gather callback failed");
+    HIP_TRY(ctx, hipMemcpyAsync(d_buf, ctx->cb_host.data(), sizeof(double) * total, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPMI_OK;
+}
+
 // ---- the ICP call, device pointers -----------------------------------------------------
 int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const double *d_tgt,
                  int64_t n_tgt64, const icpmi_config *cfg, icpmi_result *result,
@@ -269,6 +311,9 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     double *partials = (double *)ctx->partials.p;
     double *hist = (double *)ctx->history.p;
 
+    StageTimer *t_total = new StageTimer(ctx, ST_TOTAL);
+    struct Closer { StageTimer *&p; ~Closer() { delete p; p = nullptr; } } close_total{t_total};
+
     // state: total = initial_transform (icp.hpp:163,178), prev_error = DBL_MAX (icp.hpp:179)
     IcpState *hs = ctx->h_state;
     memset(hs, 0, sizeof(*hs));
@@ -288,8 +333,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         const int row0 = std::min(m, ctx->rank * per), row1 = std::min(m, row0 + per);
         // rows land at their global offset inside `gathered`, so the gather is in place
         if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, row0, row1, gathered))) return rc;
-        RCCL_TRY(ctx, ctx->rccl.AllGather(gathered + 3 * (size_t)ctx->rank * per, gathered,
-                                          3 * (size_t)per, ncclDouble, ctx->comm, s));
+        if ((rc = exchange_allgather(ctx, gathered, 3 * (size_t)per))) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(nrm, gathered, sizeof(double) * 3 * (size_t)m,
                                     hipMemcpyDeviceToDevice, s));
     } else {
@@ -313,8 +357,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
             if (ctx->n_ranks > 1) {
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, partials, rblocks, n,
                                    ctx->d_state);
-                RCCL_TRY(ctx, ctx->rccl.AllReduce(ctx->d_state->sums, ctx->d_state->sums, kNumSums,
-                                                  ncclDouble, ncclSum, ctx->comm, s));
+                if ((r2 = exchange_allreduce(ctx, ctx->d_state->sums, kNumSums))) return r2;
                 hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, ctx->d_state, hist, final_pass);
             } else {
                 hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(256), 0, s, partials, rblocks, n,
@@ -329,6 +372,8 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         return ICPMI_OK;
     };
 
+    StageTimer *t_loop = new StageTimer(ctx, ST_LOOP);
+    struct Closer2 { StageTimer *&p; ~Closer2() { delete p; p = nullptr; } } close_loop{t_loop};
     for (int it = 0; it < max_it; ++it) {
         if (it >= kLag) {
             const int slot = (it - kLag) % kFlagRing;
@@ -344,6 +389,10 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // post-loop evaluation (icp.hpp:235-252): a full pass after exhaustion, a re-statement
     // of the last error after a convergence break
     if ((rc = iteration(1))) return rc;
+    delete t_loop;
+    t_loop = nullptr;
+    delete t_total;
+    t_total = nullptr;
 
     HIP_TRY(ctx, hipMemcpyAsync(hs, ctx->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -654,6 +703,22 @@ int icpmi_comm_init(icpmi_ctx *ctx, int32_t n_ranks, int32_t rank, const void *i
     return ICPMI_OK;
 }
 
+int icpmi_comm_init_callbacks(icpmi_ctx *ctx, int32_t n_ranks, int32_t rank,
+                              icpmi_allreduce_fn allreduce, icpmi_allgather_fn allgather, void *user)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ctx, ICPMI_ERR_ARG, "bad rank %d of %d", rank, n_ranks);
+    if (ctx->comm || ctx->cb_allreduce) return fail(ctx, ICPMI_ERR_ARG, "communicator already initialised");
+    if (n_ranks > 1 && (!allreduce || !allgather)) return fail(ctx, ICPMI_ERR_NULL, "callback is NULL");
+    ctx->cb_allreduce = allreduce;
+    ctx->cb_allgather = allgather;
+    ctx->cb_user = user;
+    ctx->n_ranks = n_ranks;
+    ctx->rank = rank;
+    return ICPMI_OK;
+}
+
 int icpmi_comm_finalize(icpmi_ctx *ctx)
 {
     int rc;
@@ -663,6 +728,9 @@ int icpmi_comm_finalize(icpmi_ctx *ctx)
         RCCL_TRY(ctx, ctx->rccl.CommDestroy(ctx->comm));
         ctx->comm = nullptr;
     }
+    ctx->cb_allreduce = nullptr;
+    ctx->cb_allgather = nullptr;
+    ctx->cb_user = nullptr;
     ctx->n_ranks = 1;
     ctx->rank = 0;
     return ICPMI_OK;

@@ -1,0 +1,58 @@
+"""Source-sharded multi-GPU registration: one process per GPU.
+
+The source cloud is cut into contiguous shards, the target (and its normals) is
+replicated, and the only per-iteration exchange is the all-reduce of 29 doubles
+(21 J^T J + 6 J^T b + sum b^2 + count).  Every rank then solves the same 6x6 system from
+the same bits, so the pose and the convergence decision need no broadcast.
+
+Transport: RCCL inside the C library (`init_rccl`), bootstrapped by broadcasting the
+128-byte unique id over torch.distributed; or host callbacks over any torch.distributed
+backend (`init_callbacks`, used with gloo to rehearse the N > 1 path).
+"""
+import numpy as np
+
+
+def shard_bounds(n, n_ranks, rank):
+    """Contiguous shard [lo, hi) of n rows for `rank`."""
+    lo = (n * rank) // n_ranks
+    hi = (n * (rank + 1)) // n_ranks
+    return lo, hi
+
+
+def init_rccl(ctx, dist, device=None):
+    """Create the library's RCCL communicator over the ranks of torch.distributed."""
+    import torch
+    n_ranks, rank = dist.get_world_size(), dist.get_rank()
+    if n_ranks == 1:
+        return
+    ident = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ident, src=0, device=device)
+    ctx.comm_init(n_ranks, rank, ident[0])
+
+
+def init_callbacks(ctx, dist):
+    """Exchange through torch.distributed collectives on host tensors (e.g. gloo)."""
+    import torch
+    n_ranks, rank = dist.get_world_size(), dist.get_rank()
+
+    def allreduce(buf):
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def allgather(buf, per):
+        mine = torch.from_numpy(buf[rank * per:(rank + 1) * per].copy())
+        parts = [torch.empty(per, dtype=torch.float64) for _ in range(n_ranks)]
+        dist.all_gather(parts, mine)
+        for r, p in enumerate(parts):
+            buf[r * per:(r + 1) * per] = p.numpy()
+
+    ctx.comm_init_callbacks(n_ranks, rank, allreduce, allgather)
+
+
+def reduce_normal_equations(local_sums, dist):
+    """Host-side statement of the exchange (used by the gloo tests): element-wise sum of
+    the 29-vector over ranks; identical bits on every rank afterwards."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(local_sums, dtype=np.float64).copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy()

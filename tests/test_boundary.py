@@ -1,0 +1,110 @@
+"""The C-ABI library loads and exports every symbol include/icp_mi355x.h declares; the
+host mirror keeps the reference's names, defaults and algebra.  No compute without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import lidar_slam_from_scratch_amd as pkg
+from lidar_slam_from_scratch_amd import build, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_library()
+    return capi.load_library()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "icp_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(icpmi_[a-z_0-9]+)\s*\(", text)) - {"icpmi_allreduce_fn", "icpmi_allgather_fn"})
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(capi.EXPORTS) == names
+
+
+def test_struct_layouts_match_header(lib):
+    assert ctypes.sizeof(capi.Options) == 16
+    assert ctypes.sizeof(capi.Config) == 8 + 16 + 128
+    assert ctypes.sizeof(capi.Result) == 128 + 8 + 8 + 8
+    cfg = capi.Config()
+    lib.icpmi_config_default(ctypes.byref(cfg))
+    assert (cfg.max_iterations, cfg.tolerance, cfg.min_error) == (50, 1e-6, 1e-9)  # types.hpp:143-148
+    assert list(cfg.initial_transform) == list(np.eye(4).reshape(16))
+    opt = capi.Options()
+    lib.icpmi_options_default(ctypes.byref(opt))
+    assert opt.normal_k == 20  # icp.hpp:170
+
+
+def test_library_carries_gfx950_code_only():
+    data = open(build.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+    for other in (b"gfx942", b"gfx90a", b"sm_90", b"nvptx"):
+        assert other not in data
+
+
+def test_create_fails_loudly_without_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.IcpError) as e:
+        capi.Context()
+    assert e.value.code == capi.ERR_NO_DEVICE
+    with pytest.raises(capi.IcpError):
+        pkg.icp_point_to_plane(np.zeros((4, 3)), np.zeros((4, 3)))
+
+
+def test_missing_library_raises(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        capi.load_library(str(tmp_path / "nope.so"))
+
+
+def test_transformation_algebra():
+    """types.hpp:74-136"""
+    from lidar_slam_from_scratch_amd import synth
+    A = pkg.Transformation(synth.make_transform((0.1, 0.2, -0.3), (1, 2, 3)))
+    B = pkg.Transformation(synth.make_transform((-0.2, 0.05, 0.1), (-1, 0.5, 2)))
+    p = np.array([0.3, -0.7, 1.1])
+    np.testing.assert_allclose((A * B).apply(p), A.apply(B.apply(p)), atol=1e-14)  # this after other
+    np.testing.assert_allclose((A * A.inverse()).matrix(), np.eye(4), atol=1e-14)
+    cloud = pkg.PointCloud(np.arange(12.0).reshape(4, 3))
+    np.testing.assert_allclose(A.apply(cloud).points(), cloud.points() @ A.R().T + A.t(), atol=0)
+    assert cloud.size() == 4 and not cloud.empty() and pkg.PointCloud().empty()
+    np.testing.assert_allclose(cloud.centered().centroid(), 0, atol=1e-15)
+
+
+def test_config_and_result_defaults():
+    c = pkg.ICPConfig()
+    assert (c.max_iterations, c.tolerance, c.min_error) == (50, 1e-6, 1e-9)
+    assert (c.initial_transform.matrix() == np.eye(4)).all()
+    r = pkg.ICPResult()
+    assert not r.converged and r.num_iterations == 0 and r.final_error == 0.0 and not r.success()
+    r.converged, r.final_error = True, 0.05
+    assert r.success()  # types.hpp:163
+
+
+def test_cpp_adapter_compiles_against_a_minimal_cloud_type(tmp_path):
+    """include/icp_mi355x.hpp (the C++ mirror of slam::icp_point_to_plane) must compile
+    and link against the library with a plain C++17 compiler."""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text(
+        '#include "icp_mi355x.hpp"\n'
+        "int main(){ icp_mi355x::PointCloud a, b; icp_mi355x::ICPConfig c;\n"
+        " try { auto r = icp_mi355x::icp_point_to_plane(a, b, c); return r.converged ? 1 : 0; }\n"
+        " catch (const std::exception&) { return 0; } }\n")
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), build.LIB_PATH, "-Wl,-rpath," + os.path.dirname(build.LIB_PATH),
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"])
+    assert subprocess.call([str(exe)]) == 0

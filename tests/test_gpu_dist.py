@@ -1,0 +1,60 @@
+"""The sharded path THROUGH THE HIP LIBRARY with two ranks on one GPU: k_finish ->
+all-reduce(29 doubles) -> k_step, and row-sliced normals + all-gather, with the exchanges
+carried by gloo host callbacks (RCCL refuses two ranks on one device; the 8-GPU RCCL run
+is the driver's).  Result must equal the single-rank GPU run and the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from lidar_slam_from_scratch_amd import capi, dist as icpdist, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    src, tgt, _ = synth.c1_room_corner(3001)
+    lo, hi = icpdist.shard_bounds(src.shape[0], world, rank)
+    ctx = capi.Context(device=0)
+    icpdist.init_callbacks(ctx, dist)
+    res, hist = ctx.align(src[lo:hi], tgt, capi.Context.make_config())
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), T=np.array(res.transformation[:]).reshape(4, 4),
+             hist=hist, conv=res.converged, iters=res.num_iterations)
+    ctx.comm_finalize()
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_align_on_one_gpu(tmp_path, oracle, gpu_ctx, world):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(world)]
+    for k in range(1, world):
+        assert (r[0]["T"] == r[k]["T"]).all() and (r[0]["hist"] == r[k]["hist"]).all()
+    from lidar_slam_from_scratch_amd import capi, synth
+    src, tgt, _ = synth.c1_room_corner(3001)
+    ref = oracle.icp_point_to_plane(src, tgt)
+    assert bool(r[0]["conv"]) == ref.converged and int(r[0]["iters"]) == ref.num_iterations
+    dt, dr = synth.pose_delta(r[0]["T"], ref.transformation)
+    assert dt < 1e-9 and dr < 1e-9
+    np.testing.assert_allclose(r[0]["hist"], ref.error_history, atol=1e-9)
+    single, shist = gpu_ctx.align(src, tgt, capi.Context.make_config())
+    assert single.num_iterations == int(r[0]["iters"])
+    np.testing.assert_allclose(np.array(single.transformation[:]).reshape(4, 4), r[0]["T"], atol=1e-12)

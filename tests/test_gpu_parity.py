@@ -1,0 +1,276 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed
+golden fixtures.  Bit-exact for indices, squared distances and normals; pose within
+1e-4 m / 1e-4 rad (BASELINE.json north_star) -- in practice ~1e-15 -- with the same
+iteration count and convergence flag.  Marked gpu: runs on the MI355X box only."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from lidar_slam_from_scratch_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-4   # north_star tolerance
+HIST_TOL = 1e-9
+
+
+def crc(a):
+    return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def T_of(res):
+    return np.array(res.transformation[:]).reshape(4, 4)
+
+
+def check_against(res, hist, ref_T, ref_conv, ref_iters, ref_hist):
+    dt, dr = synth.pose_delta(T_of(res), ref_T)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+    assert bool(res.converged) == bool(ref_conv)
+    assert res.num_iterations == int(ref_iters)
+    assert len(hist) == len(ref_hist)
+    np.testing.assert_allclose(hist, ref_hist, rtol=0, atol=HIST_TOL)
+    assert res.final_error == hist[-1]
+    return dt, dr
+
+
+# ------------------------------------------------------------------ nearest neighbour
+@pytest.mark.parametrize("n_qry,n_tgt,seed", [(1, 1, 0), (1, 2, 1), (7, 3, 2), (513, 255, 3),
+                                               (512, 256, 4), (1000, 257, 5), (5000, 5000, 6),
+                                               (20011, 19997, 7)])
+def test_nearest_batch_bit_exact(gpu_ctx, oracle, n_qry, n_tgt, seed):
+    rng = np.random.default_rng(seed)
+    tgt = rng.uniform(-50, 50, (n_tgt, 3))
+    qry = rng.uniform(-50, 50, (n_qry, 3))
+    idx, d2 = gpu_ctx.nearest_batch(tgt, qry)
+    oidx, od2 = oracle.KDTree(tgt).nearest_batch(qry)
+    assert (idx == oidx).all()
+    assert (d2 == od2).all()  # same fp64 operation order, no FMA
+
+
+def test_nearest_batch_on_surfaces_and_self(gpu_ctx, oracle):
+    src, tgt, _ = synth.c1_room_corner()
+    idx, d2 = gpu_ctx.nearest_batch(tgt, src)
+    oidx, od2 = oracle.KDTree(tgt).nearest_batch(src)
+    assert (idx == oidx).all() and (d2 == od2).all()
+    # idempotence: every target's nearest target is itself at distance 0
+    idx, d2 = gpu_ctx.nearest_batch(tgt, tgt)
+    assert (idx == np.arange(tgt.shape[0])).all() and (d2 == 0).all()
+
+
+def test_nearest_batch_duplicates_pick_lowest_index(gpu_ctx):
+    tgt = np.array([[1.0, 2, 3], [4, 5, 6], [1, 2, 3], [4, 5, 6]])
+    qry = np.array([[1.0, 2, 3.1], [4, 5, 5.9]])
+    idx, _ = gpu_ctx.nearest_batch(tgt, qry)
+    assert list(idx) == [0, 1]
+
+
+def test_nearest_batch_large_properties(gpu_ctx):
+    """BASELINE.json full size (100k -> 100k): size-independent properties only."""
+    src, tgt, _ = synth.c3_uniform()
+    idx, d2 = gpu_ctx.nearest_batch(tgt, src)
+    assert idx.min() >= 0 and idx.max() < tgt.shape[0]
+    diff = tgt[idx] - src
+    assert (((diff[:, 0] ** 2 + diff[:, 1] ** 2) + diff[:, 2] ** 2) == d2).all()
+    rng = np.random.default_rng(0)
+    for _ in range(8):  # no sampled target may be closer than the reported neighbour
+        j = rng.integers(0, tgt.shape[0], size=src.shape[0])
+        dj = ((tgt[j] - src) ** 2).sum(axis=1)
+        assert (dj >= d2 * (1 - 1e-15)).all()
+    from scipy.spatial import cKDTree
+    _, ii = cKDTree(tgt).query(src[:20000])
+    assert (idx[:20000] == ii).all()
+
+
+# ------------------------------------------------------------------ normals
+@pytest.mark.parametrize("k", [3, 8, 20, 33])
+def test_normals_bit_exact(gpu_ctx, oracle, k):
+    _, tgt, _ = synth.c1_room_corner(3000)
+    got = gpu_ctx.estimate_normals(tgt, k)
+    want = oracle.estimate_normals(tgt, None, k)
+    assert np.abs(got - want).max() <= 1e-12
+    assert (got == want).all(axis=1).mean() == 1.0
+
+
+def test_normals_few_points(gpu_ctx):
+    tgt = np.array([[0.0, 0, 0], [1, 0, 0]])
+    assert (gpu_ctx.estimate_normals(tgt, 20) == [[0, 0, 1], [0, 0, 1]]).all()  # icp.hpp:34-37
+    tri = np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0]])
+    n = gpu_ctx.estimate_normals(tri, 20)
+    np.testing.assert_allclose(np.abs(n), [[0, 0, 1]] * 3, atol=1e-15)
+
+
+def test_normals_golden_crc(gpu_ctx):
+    g = np.load(os.path.join(GOLD, "c2_lidar_pair.npz"))
+    _, tgt, _ = synth.c2_lidar_pair()
+    assert crc(tgt) == g["tgt_crc"]
+    got = gpu_ctx.estimate_normals(tgt, 20)
+    assert (got[:32] == g["normals_head"]).all()
+    assert crc(got) == g["normals_crc"]
+
+
+# ------------------------------------------------------------------ solve / transform
+def test_solve_point_to_plane(gpu_ctx, oracle):
+    src, tgt, _ = synth.c1_room_corner()
+    tree = oracle.KDTree(tgt)
+    idx, _ = tree.nearest_batch(src)
+    nrm = oracle.estimate_normals(tgt, tree, 20)
+    got = gpu_ctx.solve_point_to_plane(src, tgt[idx], nrm[idx])
+    want = oracle.solve_point_to_plane(src, tgt[idx], nrm[idx])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)  # summation order differs
+    assert (got[3] == [0, 0, 0, 1]).all()
+
+
+def test_solve_single_plane_is_finite(gpu_ctx, oracle):
+    rng = np.random.default_rng(9)
+    src = np.c_[rng.uniform(-5, 5, (400, 2)), np.zeros(400)]
+    nrm = np.tile([0.0, 0, 1.0], (400, 1))
+    got = gpu_ctx.solve_point_to_plane(src, src + [0, 0, 0.01], nrm)
+    assert np.isfinite(got).all() and abs(got[2, 3] - 0.01) < 1e-12
+    assert got[0, 3] == 0 and got[1, 3] == 0
+
+
+def test_transform_points_bit_exact(gpu_ctx):
+    src, _, T = synth.c1_room_corner(4097)
+    got = gpu_ctx.transform_points(T, src)
+    x, y, z = src[:, 0], src[:, 1], src[:, 2]
+    for r in range(3):
+        want = ((x * T[r, 0] + y * T[r, 1]) + z * T[r, 2]) + T[r, 3]
+        assert (got[:, r] == want).all()
+    back = gpu_ctx.transform_points(synth.invert_transform(T), got)
+    np.testing.assert_allclose(back, src, atol=1e-13)
+
+
+# ------------------------------------------------------------------ full registration
+CASES = {
+    "c1_room_corner": lambda: synth.c1_room_corner(),
+    "kat1_exact": lambda: synth.kat1_exact_pair(),
+    "c2_lidar_pair": lambda: synth.c2_lidar_pair(),
+    "c3_small_20k": lambda: synth.c3_uniform(20000, seed=14, perm_seed=15),
+    "c3_uniform_100k": lambda: synth.c3_uniform(),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_align_matches_golden(gpu_ctx, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    src, tgt, _ = CASES[name]()
+    assert crc(src) == g["src_crc"] and crc(tgt) == g["tgt_crc"], "generator drifted"
+    cfg = capi.Context.make_config(int(g["max_iterations"]), float(g["tolerance"]), float(g["min_error"]))
+    res, hist = gpu_ctx.align(src, tgt, cfg)
+    dt, dr = check_against(res, hist, g["transformation"], g["converged"], g["num_iterations"],
+                           g["error_history"])
+    assert dt < 1e-9 and dr < 1e-9  # far inside the north_star tolerance
+
+
+def test_align_matches_oracle_live(gpu_ctx, oracle):
+    src, tgt, _ = synth.c1_room_corner(2500)
+    for kw in (dict(max_iterations=50, tolerance=1e-6, min_error=1e-9),
+               dict(max_iterations=3, tolerance=0.0, min_error=0.0),
+               dict(max_iterations=1, tolerance=1e-6, min_error=1e-9),
+               dict(max_iterations=0, tolerance=1e-6, min_error=1e-9)):
+        ref = oracle.icp_point_to_plane(src, tgt, **kw)
+        res, hist = gpu_ctx.align(src, tgt, capi.Context.make_config(**kw))
+        check_against(res, hist, ref.transformation, ref.converged, ref.num_iterations, ref.error_history)
+
+
+def test_align_initial_transform(gpu_ctx, oracle):
+    src, tgt, T = synth.c1_room_corner(2500)
+    T0 = synth.make_transform((0.005, -0.01, 0.02), (0.05, -0.02, 0.0))
+    ref = oracle.icp_point_to_plane(src, tgt, initial_transform=T0)
+    res, hist = gpu_ctx.align(src, tgt, capi.Context.make_config(initial_transform=T0))
+    check_against(res, hist, ref.transformation, ref.converged, ref.num_iterations, ref.error_history)
+
+
+def test_align_control_flow_invariants(gpu_ctx):
+    """SURVEY section 8a R9 invariants."""
+    _, tgt, _ = synth.c1_room_corner(1500)
+    res, hist = gpu_ctx.align(tgt, tgt, capi.Context.make_config())  # min_error stop at iter 0
+    assert res.converged and res.num_iterations == 1 and list(hist) == [0.0, 0.0]
+    assert (T_of(res) == np.eye(4)).all()
+    src, tgt, _ = synth.c1_room_corner()
+    res, hist = gpu_ctx.align(src, tgt, capi.Context.make_config())  # tolerance stop
+    k = res.loop_iterations - 1
+    assert res.converged and len(hist) == k + 2 and res.num_iterations == k + 1
+    assert res.final_error == hist[k]
+    res, hist = gpu_ctx.align(src, tgt, capi.Context.make_config(4, 0.0, 0.0))  # exhaustion
+    assert not res.converged and res.num_iterations == 4 and len(hist) == 5
+
+
+def test_align_ragged_sizes_and_reuse(gpu_ctx, oracle):
+    """Clouds of different sizes through one context (workspace reuse, odometry pattern
+    slam_node.cpp:132-145: the target of call t+1 is the source of call t)."""
+    frames = [synth.lidar_frame(f, beams=32, azimuths=600) for f in range(3)]
+    for prev, cur in zip(frames[:-1], frames[1:]):
+        ref = oracle.icp_point_to_plane(cur, prev)
+        res, hist = gpu_ctx.align(cur, prev, capi.Context.make_config())
+        check_against(res, hist, ref.transformation, ref.converged, ref.num_iterations, ref.error_history)
+
+
+def test_align_run_to_run_bit_stable(gpu_ctx):
+    src, tgt, _ = synth.c1_room_corner(3000)
+    cfg = capi.Context.make_config()
+    a, ha = gpu_ctx.align(src, tgt, cfg)
+    b, hb = gpu_ctx.align(src, tgt, cfg)
+    assert (T_of(a) == T_of(b)).all() and (ha == hb).all()
+
+
+def test_host_mirror_api(gpu_ctx, oracle):
+    import lidar_slam_from_scratch_amd as pkg
+    src, tgt, _ = synth.c1_room_corner(2000)
+    ref = oracle.icp_point_to_plane(src, tgt)
+    r = pkg.icp_point_to_plane(pkg.PointCloud(src), pkg.PointCloud(tgt), pkg.ICPConfig(), ctx=gpu_ctx)
+    assert r.converged == ref.converged and r.num_iterations == ref.num_iterations
+    np.testing.assert_allclose(r.transformation.matrix(), ref.transformation, atol=1e-9)
+    r2 = pkg.ICP(pkg.ICPConfig(max_iterations=30), ctx=gpu_ctx).align(src, tgt)
+    assert r2.num_iterations == r.num_iterations and r2.success() == (r.converged and r.final_error < 0.1)
+    nn = pkg.NearestNeighborSearch(tgt, ctx=gpu_ctx)
+    matched, dist = nn.find_correspondences(src)
+    oidx, od2 = oracle.KDTree(tgt).nearest_batch(src)
+    assert (matched == tgt[oidx]).all() and (dist == np.sqrt(od2)).all()
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_error_codes(gpu_ctx):
+    cfg = capi.Context.make_config()
+    pts = np.zeros((4, 3))
+    empty = np.zeros((0, 3))
+    with pytest.raises(capi.IcpError) as e:
+        gpu_ctx.align(empty, pts, cfg)
+    assert e.value.code == capi.ERR_EMPTY_SOURCE
+    with pytest.raises(capi.IcpError) as e:
+        gpu_ctx.align(pts, empty, cfg)
+    assert e.value.code == capi.ERR_EMPTY_TARGET
+    with pytest.raises(capi.IcpError) as e:
+        gpu_ctx.nearest_batch(empty, pts)
+    assert e.value.code == capi.ERR_EMPTY_TARGET
+    with pytest.raises(capi.IcpError) as e:
+        gpu_ctx.estimate_normals(pts, 65)
+    assert e.value.code == capi.ERR_ARG
+    import ctypes as C
+    res = capi.Result()
+    hist = np.zeros(4)
+    rc = gpu_ctx._lib.icpmi_align(gpu_ctx._h, pts.ctypes.data_as(C.POINTER(C.c_double)), 4,
+                                  pts.ctypes.data_as(C.POINTER(C.c_double)), 4, C.byref(cfg),
+                                  C.byref(res), hist.ctypes.data_as(C.POINTER(C.c_double)), 4)
+    assert rc == capi.ERR_CAPACITY and b"needs 51" in gpu_ctx._lib.icpmi_last_error(gpu_ctx._h)
+    rc = gpu_ctx._lib.icpmi_align(gpu_ctx._h, None, 4, pts.ctypes.data_as(C.POINTER(C.c_double)), 4,
+                                  C.byref(cfg), C.byref(res), hist.ctypes.data_as(C.POINTER(C.c_double)), 51)
+    assert rc == capi.ERR_NULL
+    import lidar_slam_from_scratch_amd as pkg
+    r = pkg.icp_point_to_plane(empty, pts, ctx=gpu_ctx, on_error="unconverged")
+    assert not r.converged and (r.transformation.matrix() == np.eye(4)).all()  # gate -> identity
+    # the context is still usable after errors
+    idx, _ = gpu_ctx.nearest_batch(np.eye(3), np.eye(3))
+    assert list(idx) == [0, 1, 2]
+
+
+def test_profile_counters(gpu_ctx):
+    src, tgt, _ = synth.c1_room_corner(2000)
+    gpu_ctx.reset_profile()
+    res, _ = gpu_ctx.align(src, tgt, capi.Context.make_config(5, 0.0, 0.0))
+    p = gpu_ctx.get_profile()
+    assert p["nn_launches"] == 6 and p["reduce_launches"] == 6 and p["normals_launches"] == 1
+    assert p["nn_ms"] > 0 and p["total_ms"] >= p["loop_ms"] > 0
+    assert p["nn_pairs"] == 6 * 2000 * 2000
