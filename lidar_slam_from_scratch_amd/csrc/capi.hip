@@ -127,24 +127,30 @@ void release(DevBuf &b)
 // ---- profiling helpers ----------------------------------------------------------------
 struct StageTimer {
     icpmi_ctx *ctx;
-    EventPair *ep = nullptr;
+    long slot = -1; // index, not pointer: the pool may reallocate while an outer timer is open
     StageTimer(icpmi_ctx *c, int stage) : ctx(c)
     {
         if (!ctx->opt.profile) return;
         if (ctx->ev_used == ctx->ev_pool.size()) {
             EventPair p;
-            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            if (hipEventCreate(&p.a) != hipSuccess) return;
+            if (hipEventCreate(&p.b) != hipSuccess) {
+                (void)hipEventDestroy(p.a);
+                return;
+            }
             p.stage = stage;
             ctx->ev_pool.push_back(p);
         }
-        ep = &ctx->ev_pool[ctx->ev_used++];
-        ep->stage = stage;
-        (void)hipEventRecord(ep->a, ctx->stream);
+        slot = (long)ctx->ev_used++;
+        ctx->ev_pool[slot].stage = stage;
+        (void)hipEventRecord(ctx->ev_pool[slot].a, ctx->stream);
     }
     ~StageTimer()
     {
-        if (ep) (void)hipEventRecord(ep->b, ctx->stream);
+        if (slot >= 0) (void)hipEventRecord(ctx->ev_pool[slot].b, ctx->stream);
     }
+    StageTimer(const StageTimer &) = delete;
+    StageTimer &operator=(const StageTimer &) = delete;
 };
 
 // call after the stream has been synchronised

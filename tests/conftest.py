@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime (ROCm 7.0); importing it before libicp_mi355x.so is
+# dlopen'ed makes the whole process use that one runtime instead of loading a second copy
+# from /opt/rocm next to it.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
