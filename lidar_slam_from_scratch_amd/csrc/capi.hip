@@ -21,6 +21,7 @@
 
 #include "../../include/icp_mi355x.h"
 #include "kernels.h"
+#include "nn_mfma.h"
 
 using namespace icpmi;
 
@@ -59,6 +60,9 @@ struct icpmi_ctx {
     int cu_count = 256;
 
     DevBuf cur, nrm, idx, part_d2, part_idx, partials, history, stage_a, stage_b, stage_c, d2out;
+    DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
+    int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
+    int nn_splits = 0;
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
     int32_t *h_flags = nullptr;    // pinned ring of done flags
@@ -156,6 +160,14 @@ struct StageTimer {
 // call after the stream has been synchronised
 void harvest_profile(icpmi_ctx *ctx)
 {
+    if (ctx->opt.profile && ctx->nn_engine == ICPMI_SEARCH_MFMA_F32 && ctx->nn_misc.p) {
+        unsigned long long cnt[2] = {0, 0};
+        if (hipMemcpy(cnt, (char *)ctx->nn_misc.p + 128, sizeof(cnt), hipMemcpyDeviceToHost) == hipSuccess) {
+            ctx->prof.nn_recheck_queries += (int64_t)cnt[0];
+            ctx->prof.nn_fallback_queries += (int64_t)cnt[1];
+            (void)hipMemset((char *)ctx->nn_misc.p + 128, 0, sizeof(cnt));
+        }
+    }
     for (size_t i = 0; i < ctx->ev_used; ++i) {
         float ms = 0.f;
         EventPair &p = ctx->ev_pool[i];
@@ -175,10 +187,59 @@ void harvest_profile(icpmi_ctx *ctx)
 
 // ---- kernel launch wrappers ------------------------------------------------------------
 
+// Choose and prepare the search engine for a target cloud (once per call: the target does
+// not move).  Both engines return the same indices; AUTO takes the MFMA engine once the
+// pair count makes its fixed costs (bounding box, operand packing, resolve) worthwhile.
+int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
+{
+    int engine = ctx->opt.search;
+    if (engine == ICPMI_SEARCH_AUTO)
+        engine = (m >= 2 * kSplitTargets && n_hint >= 1024) ? ICPMI_SEARCH_MFMA_F32 : ICPMI_SEARCH_EXACT_F64;
+    ctx->nn_engine = engine;
+    if (engine != ICPMI_SEARCH_MFMA_F32) return ICPMI_OK;
+    const int splits = (m + kSplitTargets - 1) / kSplitTargets;
+    ctx->nn_splits = splits;
+    int rc;
+    const int bblocks = std::max(1, std::min(256, (m + 255) / 256));
+    if ((rc = reserve(ctx, ctx->bpack, sizeof(float4) * 32 * 64 * (size_t)splits))) return rc;
+    if ((rc = reserve(ctx, ctx->bbox_part, sizeof(double) * 6 * (size_t)bblocks))) return rc;
+    if ((rc = reserve(ctx, ctx->nn_misc, 256))) return rc;
+    NnFrame *frame = (NnFrame *)ctx->nn_misc.p;
+    hipStream_t s = ctx->stream;
+    StageTimer t(ctx, ST_NORMALS + 100); // setup: not attributed to a stage
+    hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_tgt, m, (double *)ctx->bbox_part.p);
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, frame);
+    hipLaunchKernelGGL(k_pack_targets, dim3((splits * 32 * 64 + 255) / 256), dim3(256), 0, s, d_tgt, m,
+                       (const NnFrame *)frame, (float4 *)ctx->bpack.p, splits);
+    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->nn_misc.p + 128, 0, 16, s));
+    HIP_TRY(ctx, hipGetLastError());
+    return ICPMI_OK;
+}
+
+int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, const double *d_tgt, int m, int *d_idx,
+                   double *d_d2, const IcpState *st)
+{
+    const int splits = ctx->nn_splits;
+    int rc;
+    if ((rc = reserve(ctx, ctx->coarse, sizeof(float2) * (size_t)splits * n))) return rc;
+    const NnFrame *frame = (const NnFrame *)ctx->nn_misc.p;
+    unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);
+    StageTimer t(ctx, ST_NN);
+    hipLaunchKernelGGL(k_nn_coarse, dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
+                       dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const float4 *)ctx->bpack.p, frame,
+                       (float2 *)ctx->coarse.p, st);
+    hipLaunchKernelGGL(k_nn_resolve, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_qry, n, d_tgt, m,
+                       (const float2 *)ctx->coarse.p, splits, frame, d_idx, d_d2, counters, st);
+    ctx->prof.nn_pairs += (double)n * (double)m;
+    HIP_TRY(ctx, hipGetLastError());
+    return ICPMI_OK;
+}
+
 // nearest neighbour of every row of d_qry among d_tgt -> d_idx (+ optional d_d2)
 int launch_nn(icpmi_ctx *ctx, const double *d_qry, int n, const double *d_tgt, int m, int *d_idx,
               double *d_d2, const IcpState *st)
 {
+    if (ctx->nn_engine == ICPMI_SEARCH_MFMA_F32) return launch_nn_mfma(ctx, d_qry, n, d_tgt, m, d_idx, d_d2, st);
     constexpr int QPT = 2;
     const int qblocks = (n + 256 * QPT - 1) / (256 * QPT);
     // enough workgroups to fill 256 CUs several times over; every split keeps >= 256 targets
@@ -329,6 +390,8 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     hs->min_error = cfg->min_error;
     hs->max_hist = max_hist;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state, hs, sizeof(IcpState), hipMemcpyHostToDevice, s));
+
+    if ((rc = prepare_nn(ctx, d_tgt, m, n))) return rc;
 
     // normals of the target (icp.hpp:169-171).  With several ranks each computes a slice of
     // rows against the full target and the slices are all-gathered.
@@ -513,7 +576,8 @@ void icpmi_destroy(icpmi_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
     for (DevBuf *b : {&ctx->cur, &ctx->nrm, &ctx->idx, &ctx->part_d2, &ctx->part_idx, &ctx->partials,
-                      &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out})
+                      &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out,
+                      &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc})
         release(*b);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -580,6 +644,7 @@ int icpmi_nearest_batch(icpmi_ctx *ctx, const double *targets_xyz, int64_t n_tgt
     hipStream_t s = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_b.p, queries_xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.p, targets_xyz, sizeof(double) * 3 * (size_t)m, hipMemcpyHostToDevice, s));
+    if ((rc = prepare_nn(ctx, (const double *)ctx->stage_c.p, m, n))) return rc;
     if ((rc = launch_nn(ctx, (const double *)ctx->stage_b.p, n, (const double *)ctx->stage_c.p, m,
                         (int *)ctx->idx.p, (double *)ctx->d2out.p, nullptr)))
         return rc;

@@ -1,0 +1,363 @@
+// nn_mfma.h -- nearest-neighbour search, engine 2: fp32 MFMA coarse pass + certified fp64
+// resolve.  Returns exactly what k_nn_f64 returns (the fp64 nearest neighbour in the
+// reference's arithmetic, kdtree.hpp:112-142) at the FP32 matrix rate instead of the
+// FP64 vector rate.
+//
+// Coarse pass (k_nn_coarse).  With both clouds centred on c and rounded to fp32
+// (P = fl32(p - c), Q = fl32(q - c)),
+//     |P - Q|^2 = |P|^2 + [Px Py Pz 1] . [-2Qx -2Qy -2Qz |Q|^2]
+// is a K = 4 contraction: one v_mfma_f32_16x16x4_f32 evaluates 16 queries x 16 targets.
+// A wave keeps 4 query tiles (64 queries) as A operands in registers and streams target
+// tiles (B operands) from LDS; a 2048-target "split" (32 KiB, already in MFMA operand
+// order in HBM) is staged once per workgroup and shared by its 8 waves.  The only VALU
+// work per MFMA is two v_min3_f32: lane l, register r keeps the running minimum of query
+// row (l>>4)*4+r against the targets of column l&15 -- a "slot" = 128 targets that are
+// CONTIGUOUS in the caller's array (tile t, column c of split s is target s*2048+c*128+t).
+// The epilogue adds |P|^2, tags each slot minimum with its column in the 4 low mantissa
+// bits and reduces the 16 columns to (smallest, second smallest): 8 bytes per query per
+// split.  No index is tracked in the loop.
+//
+// Resolve (k_nn_resolve), all fp64 in the reference's operation order.  Per query: take the
+// split/column with the smallest coarse value, evaluate its 128 targets exactly -> D.  Every
+// target with exact distance <= D has a coarse value <= tau = D + E, where E bounds the
+// fp32 error (derivation below).  Every other slot whose recorded minimum is <= tau is
+// evaluated exactly too (whole split when its second-smallest column is <= tau).  The
+// result is the exact minimum, ties to the lowest index: bit-identical to k_nn_f64.
+//
+// Error bound.  u = 2^-24.  Let a >= |P| + |Q|.
+//   coordinate rounding: |P-(p-c)| <= u|p-c|, same for Q, so
+//        | |P-Q|^2 - |p-q|^2 | <= eps (2 d + eps),  eps = u a (1 + 1e-6),  d = |p-q|
+//   arithmetic: fl32(|Q|^2) (1 rounding of an exact fp64 value), 4 chained FMAs in the MFMA
+//        (guide: bitwise a k-ordered fmaf chain), fl32(|P|^2) formed with 3 roundings, 1
+//        final add: every intermediate is bounded by a^2, so <= 9 u a^2; 16 u a^2 is used.
+//   column tag: < 2^-20 relative on the stored minimum.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace icpmi {
+
+constexpr int kSplitTiles = 128;                  // target tiles (16 targets each) per split
+constexpr int kSplitTargets = kSplitTiles * 16;   // 2048
+constexpr int kSlotTargets = kSplitTiles;         // targets per (split, column) slot
+constexpr int kCoarseQT = 4;                      // query tiles per wave
+constexpr int kCoarseThreads = 512;               // 8 waves
+constexpr int kCoarseQueries = 16 * kCoarseQT * (kCoarseThreads / 64); // 512 per workgroup
+constexpr float kBig = 3.0e38f;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct NnFrame {
+    double c[3];     // centre both clouds are expressed about
+    double rq;       // upper bound of |Q| over all targets (inflated)
+    double lo[3], hi[3];
+};
+
+// ---- bounding box of the target -> frame -------------------------------------------------
+__global__ __launch_bounds__(256) void k_bbox_partial(const double *__restrict__ pts, int m,
+                                                      double *__restrict__ part /*[grid][6]*/)
+{
+    double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256)
+        for (int a = 0; a < 3; ++a) {
+            const double v = pts[3 * i + a];
+            lo[a] = v < lo[a] ? v : lo[a];
+            hi[a] = v > hi[a] ? v : hi[a];
+        }
+    __shared__ double red[4][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int a = 0; a < 3; ++a) {
+        double l = lo[a], h = hi[a];
+        for (int off = 32; off > 0; off >>= 1) {
+            const double l2 = __shfl_down(l, off, 64), h2 = __shfl_down(h, off, 64);
+            l = l2 < l ? l2 : l;
+            h = h2 > h ? h2 : h;
+        }
+        if (lane == 0) {
+            red[wave][a] = l;
+            red[wave][3 + a] = h;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        double v = red[0][a];
+        for (int w = 1; w < 4; ++w) v = a < 3 ? (red[w][a] < v ? red[w][a] : v) : (red[w][a] > v ? red[w][a] : v);
+        part[blockIdx.x * 6 + a] = v;
+    }
+}
+
+__global__ void k_bbox_final(const double *__restrict__ part, int nblocks, NnFrame *frame)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
+    for (int b = 0; b < nblocks; ++b)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = part[b * 6 + a] < lo[a] ? part[b * 6 + a] : lo[a];
+            hi[a] = part[b * 6 + 3 + a] > hi[a] ? part[b * 6 + 3 + a] : hi[a];
+        }
+    double h2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        frame->lo[a] = lo[a];
+        frame->hi[a] = hi[a];
+        frame->c[a] = 0.5 * (lo[a] + hi[a]);
+        const double h = 0.5 * (hi[a] - lo[a]);
+        h2 += h * h;
+    }
+    frame->rq = sqrt(h2) * (1.0 + 1e-6) + 1e-300;
+}
+
+// ---- targets -> MFMA B operands, split-major, 4 tiles per float4 --------------------------
+// Bpack[(s*32 + t4)*64 + lane].{x,y,z,w}: tile t = 4*t4 + e, k = lane>>4, column = lane&15,
+// target j = s*2048 + column*128 + t.  Padding targets get (0,0,0,kBig): never the minimum.
+__global__ __launch_bounds__(256) void k_pack_targets(const double *__restrict__ tgt, int m,
+                                                      const NnFrame *__restrict__ frame,
+                                                      float4 *__restrict__ Bpack, int splits)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= splits * 32 * 64) return;
+    const int lane = g & 63, t4 = (g >> 6) & 31, s = g >> 11;
+    const int col = lane & 15, k = lane >> 4;
+    float v[4];
+    for (int e = 0; e < 4; ++e) {
+        const int t = 4 * t4 + e;
+        const long j = (long)s * kSplitTargets + col * kSlotTargets + t;
+        if (j >= m) {
+            v[e] = k < 3 ? 0.0f : kBig;
+        } else if (k < 3) {
+            v[e] = -2.0f * (float)(tgt[3 * j + k] - frame->c[k]);
+        } else {
+            const double qx = (double)(float)(tgt[3 * j] - frame->c[0]);
+            const double qy = (double)(float)(tgt[3 * j + 1] - frame->c[1]);
+            const double qz = (double)(float)(tgt[3 * j + 2] - frame->c[2]);
+            v[e] = (float)((qx * qx + qy * qy) + qz * qz);
+        }
+    }
+    Bpack[g] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ---- coarse pass ---------------------------------------------------------------------------
+__device__ __forceinline__ float min3f(float a, float b, float c)
+{
+    return __builtin_fminf(__builtin_fminf(a, b), c); // -> v_min3_f32
+}
+
+__global__ __launch_bounds__(kCoarseThreads, 4) void k_nn_coarse(
+    const double *__restrict__ qry, int n, const float4 *__restrict__ Bpack,
+    const NnFrame *__restrict__ frame, float2 *__restrict__ coarse /*[split][n]*/,
+    const IcpState *__restrict__ st)
+{
+    if (st && st->done) return;
+    __shared__ float4 ldsB[32 * 64]; // 32 KiB
+    const int s = blockIdx.y;
+    {
+        const float4 *src = Bpack + (size_t)s * (32 * 64);
+#pragma unroll
+        for (int e = 0; e < (32 * 64) / kCoarseThreads; ++e)
+            ldsB[threadIdx.x + e * kCoarseThreads] = src[threadIdx.x + e * kCoarseThreads];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = blockIdx.x * kCoarseQueries + wave * (16 * kCoarseQT);
+    const double c0 = frame->c[0], c1 = frame->c[1], c2 = frame->c[2];
+
+    // A operands: lane l holds component k = l>>4 of query row l&15; k == 3 is the constant 1
+    float a[kCoarseQT];
+    {
+        const int row = lane & 15, k = lane >> 4;
+        const double ck = k == 0 ? c0 : (k == 1 ? c1 : c2);
+#pragma unroll
+        for (int t = 0; t < kCoarseQT; ++t) {
+            int i = q0 + t * 16 + row;
+            i = i < n ? i : n - 1;
+            a[t] = k < 3 ? (float)(qry[3 * i + k] - ck) : 1.0f;
+        }
+    }
+    f32x4 m[kCoarseQT];
+#pragma unroll
+    for (int t = 0; t < kCoarseQT; ++t) m[t] = (f32x4){kBig, kBig, kBig, kBig};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+#pragma unroll 2
+    for (int t4 = 0; t4 < 32; ++t4) {
+        const float4 b = ldsB[t4 * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < kCoarseQT; ++t) {
+            const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.x, zero, 0, 0, 0);
+            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.y, zero, 0, 0, 0);
+            const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.z, zero, 0, 0, 0);
+            const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.w, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                m[t][r] = min3f(m[t][r], d0[r], d1[r]);
+                m[t][r] = min3f(m[t][r], d2[r], d3[r]);
+            }
+        }
+    }
+
+    // epilogue: + |P|^2, tag column, 16-lane top-2, one (min, second) pair per query
+    const int g = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int t = 0; t < kCoarseQT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int iq = q0 + t * 16 + g * 4 + r;
+            const int ic = iq < n ? iq : n - 1;
+            const float px = (float)(qry[3 * ic] - c0), py = (float)(qry[3 * ic + 1] - c1),
+                        pz = (float)(qry[3 * ic + 2] - c2);
+            const float pn = (px * px + py * py) + pz * pz;
+            const float v = m[t][r] + pn;
+            float v1 = __uint_as_float((__float_as_uint(v) & 0xFFFFFFF0u) | (unsigned)col);
+            float v2 = kBig;
+#pragma unroll
+            for (int x = 1; x < 16; x <<= 1) {
+                const float o1 = __shfl_xor(v1, x, 16), o2 = __shfl_xor(v2, x, 16);
+                const float hi = __builtin_fmaxf(v1, o1);
+                v1 = __builtin_fminf(v1, o1);
+                v2 = min3f(hi, v2, o2);
+            }
+            if (col == 0 && iq < n) coarse[(size_t)s * n + iq] = make_float2(v1, v2);
+        }
+    }
+}
+
+// ---- resolve ---------------------------------------------------------------------------------
+// wave-wide argmin of (d, j): smaller d, then smaller j; result valid in every lane
+__device__ __forceinline__ void wave_argmin(double &d, int &j)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_xor(d, off, 64);
+        const int oj = __shfl_xor(j, off, 64);
+        if (od < d || (od == d && oj < j)) {
+            d = od;
+            j = oj;
+        }
+    }
+}
+
+// exact scan of targets [j0, j0+len) for the query (px,py,pz), all lanes cooperate
+__device__ __forceinline__ void scan_range(const double *__restrict__ tgt, int m, int j0, int len,
+                                           double px, double py, double pz, int lane, double &bd,
+                                           int &bj)
+{
+    double d = 1.7976931348623157e308;
+    int j = 0x7fffffff;
+    for (int o = lane; o < len; o += 64) {
+        const int jj = j0 + o;
+        if (jj < m) {
+            const double dd = sqdist(tgt[3 * jj], tgt[3 * jj + 1], tgt[3 * jj + 2], px, py, pz);
+            if (dd < d) { // ascending jj: strict keeps the lowest index
+                d = dd;
+                j = jj;
+            }
+        }
+    }
+    wave_argmin(d, j);
+    if (d < bd || (d == bd && j < bj)) {
+        bd = d;
+        bj = j;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ qry, int n,
+                                                    const double *__restrict__ tgt, int m,
+                                                    const float2 *__restrict__ coarse, int splits,
+                                                    const NnFrame *__restrict__ frame,
+                                                    int *__restrict__ idx, double *__restrict__ d2out,
+                                                    unsigned long long *__restrict__ counters,
+                                                    const IcpState *__restrict__ st)
+{
+    if (st && st->done) return;
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = wave_global * 64 + lane; // lane-per-query for the bookkeeping phases
+    const bool valid = i < n;
+    const int ic = valid ? i : n - 1;
+    const double px = qry[3 * ic], py = qry[3 * ic + 1], pz = qry[3 * ic + 2];
+
+    // phase 1: smallest coarse value over the splits
+    float best = kBig;
+    int bs = 0;
+    for (int s = 0; s < splits; ++s) {
+        const float v = coarse[(size_t)s * n + ic].x;
+        if (v < best) {
+            best = v;
+            bs = s;
+        }
+    }
+    const int bcol = (int)(__float_as_uint(best) & 15u);
+
+    // phase 2: exact evaluation of each query's winning slot (wave-cooperative)
+    double bd = 1.7976931348623157e308;
+    int bj = 0x7fffffff;
+    const unsigned long long vmask = __ballot(valid);
+    for (int L = 0; L < 64; ++L) {
+        if (!((vmask >> L) & 1ull)) continue; // wave-uniform
+        const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
+        const int s = __shfl(bs, L, 64), c = __shfl(bcol, L, 64);
+        double d = 1.7976931348623157e308;
+        int j = 0x7fffffff;
+        scan_range(tgt, m, s * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
+        if (lane == L) {
+            bd = d;
+            bj = j;
+        }
+    }
+
+    // phase 3: certificate.  tau bounds the coarse value of any target at distance <= bd
+    const double dx = px - frame->c[0], dy = py - frame->c[1], dz = pz - frame->c[2];
+    const double a = sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + frame->rq;
+    const double u = 5.9604644775390625e-08; // 2^-24
+    const double eps = u * a * (1.0 + 1e-6);
+    double tau = bd + eps * (2.0 * sqrt(bd) + eps) + 16.0 * u * a * a;
+    tau = tau * (1.0 + 4e-6) + 1e-300; // column tag (2^-20) + slack for this fp64 evaluation
+    // round up: next float above the nearest-rounded value (tau > 0)
+    const float tauf = __uint_as_float(__float_as_uint((float)tau) + 1u);
+
+    unsigned extra_slots = 0, extra_splits = 0;
+    for (int s = 0; s < splits; ++s) {
+        const float2 v = coarse[(size_t)s * n + ic];
+        const bool whole = valid && v.y <= tauf;               // a second column is inside the bound
+        const bool slot = valid && !whole && s != bs && v.x <= tauf;
+        unsigned long long pend = __ballot(whole || slot);
+        while (pend) {                                         // rare; wave-uniform loop
+            const int L = __ffsll((long long)pend) - 1;
+            pend &= pend - 1;
+            const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
+            const int w = __shfl((int)whole, L, 64);
+            const int c = __shfl((int)(__float_as_uint(v.x) & 15u), L, 64);
+            double d = 1.7976931348623157e308;
+            int j = 0x7fffffff;
+            if (w) scan_range(tgt, m, s * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
+            else scan_range(tgt, m, s * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
+            if (lane == L) {
+                if (d < bd || (d == bd && j < bj)) {
+                    bd = d;
+                    bj = j;
+                }
+                if (w) ++extra_splits;
+                else ++extra_slots;
+            }
+        }
+    }
+    if (valid) {
+        idx[i] = bj;
+        if (d2out) d2out[i] = bd;
+    }
+    if (counters) {
+        unsigned es = extra_slots, ef = extra_splits;
+        for (int off = 32; off > 0; off >>= 1) {
+            es += __shfl_down(es, off, 64);
+            ef += __shfl_down(ef, off, 64);
+        }
+        if (lane == 0 && (es | ef)) {
+            atomicAdd(&counters[0], (unsigned long long)es);
+            atomicAdd(&counters[1], (unsigned long long)ef);
+        }
+    }
+}
+
+} // namespace icpmi
