@@ -266,6 +266,45 @@ def test_error_codes(gpu_ctx):
     assert list(idx) == [0, 1, 2]
 
 
+def test_mfma_engine_certificate_paths(gpu_ctx, oracle):
+    """Inputs that force the resolve kernel's rare branches (a passing check on benign data
+    never exercises them): many targets whose distances to the query differ by less than
+    the fp32 bound -- in the same column slot, in other columns of the split, and in other
+    splits -- plus queries far outside the target's bounding box."""
+    rng = np.random.default_rng(77)
+    m = 3 * 2048 + 77
+    tgt = rng.uniform(-60, 60, (m, 3))
+    qry = rng.uniform(-60, 60, (512, 3))
+    # a shell of near-equidistant targets around the first 64 queries, spread over slots
+    for q in range(64):
+        dirs = rng.normal(size=(24, 3))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        radius = 0.05 * (1.0 + 1e-7 * rng.uniform(-1, 1, size=(24, 1)))
+        where = rng.choice(m, size=24, replace=False)
+        tgt[where] = qry[q] + dirs * radius
+    qry[64:96] *= 40.0   # far outside the box: large |P| -> large bound
+    idx, d2 = gpu_ctx.nearest_batch(tgt, qry)
+    oidx, od2 = oracle.nearest_batch_brute(tgt, qry)
+    assert (idx == oidx).all() and (d2 == od2).all()
+    if gpu_ctx.engine == "mfma_f32":
+        gpu_ctx.reset_profile()
+        gpu_ctx.nearest_batch(tgt, qry)
+        p = gpu_ctx.get_profile()
+        assert p["nn_recheck_queries"] + p["nn_fallback_queries"] > 0  # the branches ran
+
+
+def test_mfma_engine_exact_ties(gpu_ctx, oracle):
+    """Exact fp64 ties across slots and splits resolve to the lowest index."""
+    rng = np.random.default_rng(5)
+    base = rng.uniform(-10, 10, (5000, 3))
+    tgt = np.concatenate([base, base[::-1], base])      # every point three times
+    qry = base[:700] + 1e-3
+    idx, d2 = gpu_ctx.nearest_batch(tgt, qry)
+    oidx, od2 = oracle.nearest_batch_brute(tgt, qry)
+    assert (idx == oidx).all() and (d2 == od2).all()
+    assert (idx < 5000).all()
+
+
 def test_profile_counters(gpu_ctx):
     src, tgt, _ = synth.c1_room_corner(2000)
     gpu_ctx.reset_profile()
