@@ -60,6 +60,7 @@ struct icpmi_ctx {
     int cu_count = 256;
 
     DevBuf cur, nrm, idx, part_d2, part_idx, partials, history, stage_a, stage_b, stage_c, d2out;
+    DevBuf knn_idx, slotmin, fb_list;         // k-NN lists, slot minima, rows for the exact fallback
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
     int nn_splits = 0;
@@ -225,9 +226,9 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, const double *d_t
     const NnFrame *frame = (const NnFrame *)ctx->nn_misc.p;
     unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);
     StageTimer t(ctx, ST_NN);
-    hipLaunchKernelGGL(k_nn_coarse, dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
+    hipLaunchKernelGGL(k_nn_coarse<0>, dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
                        dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const float4 *)ctx->bpack.p, frame,
-                       (float2 *)ctx->coarse.p, st);
+                       (float2 *)ctx->coarse.p, (float *)nullptr, st);
     hipLaunchKernelGGL(k_nn_resolve, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_qry, n, d_tgt, m,
                        (const float2 *)ctx->coarse.p, splits, frame, d_idx, d_d2, counters, st);
     ctx->prof.nn_pairs += (double)n * (double)m;
@@ -266,16 +267,48 @@ int reduce_blocks(const icpmi_ctx *ctx, int n)
     return std::max(1, std::min(ctx->cu_count, (n + 255) / 256));
 }
 
+// normals of rows [row0,row1) of d_pts against all m points (icp.hpp:23-67): k-NN lists
+// (MFMA coarse + exact resolve, or the exact fp64 kernel) then PCA.  prepare_nn() must have
+// run for d_pts.
 int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, int row1,
                    double *d_normals)
 {
-    constexpr int BLOCK = 128;
     const int rows = row1 - row0;
     if (rows <= 0) return ICPMI_OK;
+    int rc;
+    if ((rc = reserve(ctx, ctx->knn_idx, sizeof(int) * (size_t)m * k))) return rc;
+    int *knn = (int *)ctx->knn_idx.p;
+    hipStream_t s = ctx->stream;
+    constexpr int BLOCK = 128;
     const size_t smem = (size_t)k * BLOCK * (sizeof(double) + sizeof(int));
+    const bool mfma = ctx->nn_engine == ICPMI_SEARCH_MFMA_F32 && k <= 32 && m >= 4 * kSplitTargets;
     StageTimer t(ctx, ST_NORMALS);
-    hipLaunchKernelGGL(k_knn_normals<BLOCK>, dim3((rows + BLOCK - 1) / BLOCK), dim3(BLOCK), smem,
-                       ctx->stream, d_pts, m, k, row0, row1, d_normals);
+    if (mfma) {
+        const int splits = ctx->nn_splits, nslots = splits * 16;
+        // bound the slot-minimum buffer (4 B x nslots per row) to ~1 GiB by chunking the rows
+        long chunk = ((1l << 30) / ((long)nslots * 4)) / kCoarseQueries * kCoarseQueries;
+        chunk = std::max<long>(kCoarseQueries, std::min<long>(chunk, ((long)rows + kCoarseQueries - 1) / kCoarseQueries * kCoarseQueries));
+        if ((rc = reserve(ctx, ctx->slotmin, sizeof(float) * (size_t)chunk * nslots))) return rc;
+        if ((rc = reserve(ctx, ctx->fb_list, sizeof(int) * ((size_t)rows + 16)))) return rc;
+        int *fb_count = (int *)ctx->fb_list.p, *fb_list = fb_count + 16;
+        HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, sizeof(int), s));
+        const NnFrame *frame = (const NnFrame *)ctx->nn_misc.p;
+        for (long c0 = row0; c0 < row1; c0 += chunk) {
+            const int nq = (int)std::min<long>(chunk, row1 - c0);
+            hipLaunchKernelGGL(k_nn_coarse<1>, dim3((nq + kCoarseQueries - 1) / kCoarseQueries, splits),
+                               dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const float4 *)ctx->bpack.p,
+                               frame, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
+            hipLaunchKernelGGL(k_knn_resolve, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, m, k, (int)c0, nq,
+                               (const float *)ctx->slotmin.p, nslots, frame, knn, fb_list, fb_count);
+        }
+        hipLaunchKernelGGL(k_knn_exact_list<BLOCK>, dim3(64), dim3(BLOCK), smem, s, d_pts, m, k, 0, 0,
+                           (const int *)fb_list, (const int *)fb_count, knn);
+    } else {
+        hipLaunchKernelGGL(k_knn_exact_list<BLOCK>, dim3((rows + BLOCK - 1) / BLOCK), dim3(BLOCK), smem, s,
+                           d_pts, m, k, row0, row1, (const int *)nullptr, (const int *)nullptr, knn);
+    }
+    hipLaunchKernelGGL(k_normals_from_knn, dim3((rows + 255) / 256), dim3(256), 0, s, d_pts, m, k, row0, row1,
+                       (const int *)knn, d_normals);
     HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;
 }
@@ -577,7 +610,8 @@ void icpmi_destroy(icpmi_ctx *ctx)
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
     for (DevBuf *b : {&ctx->cur, &ctx->nrm, &ctx->idx, &ctx->part_d2, &ctx->part_idx, &ctx->partials,
                       &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out,
-                      &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc})
+                      &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin,
+                      &ctx->fb_list})
         release(*b);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -669,6 +703,7 @@ int icpmi_estimate_normals(icpmi_ctx *ctx, const double *points_xyz, int64_t n, 
     if ((rc = reserve(ctx, ctx->nrm, sizeof(double) * 3 * (size_t)m))) return rc;
     hipStream_t s = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.p, points_xyz, sizeof(double) * 3 * (size_t)m, hipMemcpyHostToDevice, s));
+    if ((rc = prepare_nn(ctx, (const double *)ctx->stage_c.p, m, m))) return rc;
     if ((rc = launch_normals(ctx, (const double *)ctx->stage_c.p, m, k, 0, m, (double *)ctx->nrm.p))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(normals_xyz, ctx->nrm.p, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));

@@ -2,7 +2,7 @@
 //
 //   k_nn_f64          exact fp64 exhaustive nearest neighbour (kdtree.hpp:43-59,112-142)
 //   k_nn_merge        min over target splits
-//   k_knn_normals     exact k-NN + PCA normal per target point (icp.hpp:23-67)
+//   (k-NN + PCA normals live in nn_mfma.h: k_knn_resolve / k_knn_exact_list / k_normals_from_knn)
 //   k_reduce          residuals + 6x6 normal-equation partial sums (icp.hpp:99-120,198-206)
 //   k_finish / k_step fixed-order final sum, error, convergence test, LDLT solve,
 //                     Rodrigues, pose accumulation (icp.hpp:207-231)
@@ -113,97 +113,6 @@ __global__ __launch_bounds__(256) void k_nn_merge(const double *__restrict__ par
     }
     idx[i] = bi;
     if (d2) d2[i] = best;
-}
-
-// ------------------------------------------------------------------------------------
-// exact k-NN + PCA normal, one target point per thread.  The k-entry list, sorted
-// ascending by (distance, index), lives in LDS as [slot][thread]; the k-th distance is
-// kept in a register as the acceptance threshold, so the common path is 8 fp64 ops and a
-// compare per pair.
-// ------------------------------------------------------------------------------------
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_knn_normals(const double *__restrict__ pts, int m, int k,
-                                                       int row0, int row1,
-                                                       double *__restrict__ normals)
-{
-    extern __shared__ double knn_smem[];
-    double *ld = knn_smem;
-    int *li = reinterpret_cast<int *>(knn_smem + (size_t)k * BLOCK);
-    const int tid = threadIdx.x;
-    const int i = row0 + blockIdx.x * BLOCK + tid;
-    const bool active = i < row1;
-    const int ic = active ? i : row0;
-    const double px = pts[3 * ic], py = pts[3 * ic + 1], pz = pts[3 * ic + 2];
-    int cnt = active ? 0 : k;
-    double thr = active ? __builtin_inf() : -1.0;
-
-#pragma unroll 4
-    for (int j = 0; j < m; ++j) {
-        const double tx = pts[3 * j], ty = pts[3 * j + 1], tz = pts[3 * j + 2];
-        const double d = sqdist(tx, ty, tz, px, py, pz);
-        if (d < thr) {
-            int pos = cnt < k ? cnt : k - 1;
-            while (pos > 0) {
-                const double prev = ld[(pos - 1) * BLOCK + tid];
-                if (!(prev > d)) break;
-                ld[pos * BLOCK + tid] = prev;
-                li[pos * BLOCK + tid] = li[(pos - 1) * BLOCK + tid];
-                --pos;
-            }
-            ld[pos * BLOCK + tid] = d;
-            li[pos * BLOCK + tid] = j;
-            if (cnt < k) ++cnt;
-            if (cnt == k) thr = ld[(k - 1) * BLOCK + tid];
-        }
-    }
-    if (!active) return;
-
-    double nx = 0.0, ny = 0.0, nz = 1.0; // icp.hpp:34-37
-    if (cnt >= 3) {
-        double cx = 0.0, cy = 0.0, cz = 0.0; // icp.hpp:40-44
-        for (int a = 0; a < cnt; ++a) {
-            const int j = li[a * BLOCK + tid];
-            cx += pts[3 * j];
-            cy += pts[3 * j + 1];
-            cz += pts[3 * j + 2];
-        }
-        const double kd = (double)cnt;
-        cx /= kd;
-        cy /= kd;
-        cz /= kd;
-        double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0; // icp.hpp:47-52
-        for (int a = 0; a < cnt; ++a) {
-            const int j = li[a * BLOCK + tid];
-            const double dx = pts[3 * j] - cx, dy = pts[3 * j + 1] - cy, dz = pts[3 * j + 2] - cz;
-            c00 += dx * dx;
-            c01 += dx * dy;
-            c02 += dx * dz;
-            c11 += dy * dy;
-            c12 += dy * dz;
-            c22 += dz * dz;
-        }
-        const double cov[6] = {c00 / kd, c01 / kd, c02 / kd, c11 / kd, c12 / kd, c22 / kd};
-        double v[3];
-        smallest_eigvec_sym3(cov, v); // icp.hpp:55-56
-        if (v[2] < 0.0) {             // icp.hpp:59-61
-            v[0] = -v[0];
-            v[1] = -v[1];
-            v[2] = -v[2];
-        }
-        const double z = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]; // icp.hpp:63
-        if (z > 0.0) {
-            const double s = __dsqrt_rn(z);
-            v[0] /= s;
-            v[1] /= s;
-            v[2] /= s;
-        }
-        nx = v[0];
-        ny = v[1];
-        nz = v[2];
-    }
-    normals[3 * i] = nx;
-    normals[3 * i + 1] = ny;
-    normals[3 * i + 2] = nz;
 }
 
 // ------------------------------------------------------------------------------------

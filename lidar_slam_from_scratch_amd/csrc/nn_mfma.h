@@ -144,10 +144,13 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
     return __builtin_fminf(__builtin_fminf(a, b), c); // -> v_min3_f32
 }
 
+// MODE 0: 1-NN epilogue -> coarse[split][n] = (tagged min, second min over columns)
+// MODE 1: k-NN epilogue  -> slotmin[query][split*16 + column], every column minimum kept
+template <int MODE>
 __global__ __launch_bounds__(kCoarseThreads, 4) void k_nn_coarse(
     const double *__restrict__ qry, int n, const float4 *__restrict__ Bpack,
     const NnFrame *__restrict__ frame, float2 *__restrict__ coarse /*[split][n]*/,
-    const IcpState *__restrict__ st)
+    float *__restrict__ slotmin /*[n][splits*16]*/, const IcpState *__restrict__ st)
 {
     if (st && st->done) return;
     __shared__ float4 ldsB[32 * 64]; // 32 KiB
@@ -209,6 +212,10 @@ __global__ __launch_bounds__(kCoarseThreads, 4) void k_nn_coarse(
                         pz = (float)(qry[3 * ic + 2] - c2);
             const float pn = (px * px + py * py) + pz * pz;
             const float v = m[t][r] + pn;
+            if (MODE == 1) {
+                if (iq < n) slotmin[(size_t)iq * (gridDim.y * 16) + s * 16 + col] = v;
+                continue;
+            }
             float v1 = __uint_as_float((__float_as_uint(v) & 0xFFFFFFF0u) | (unsigned)col);
             float v2 = kBig;
 #pragma unroll
@@ -358,6 +365,211 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
             atomicAdd(&counters[1], (unsigned long long)ef);
         }
     }
+}
+
+// ---- k-NN on the same coarse pass ---------------------------------------------------------------
+// Resolve for the k nearest neighbours of target row i among all targets (icp.hpp:32,
+// kdtree.hpp:65-78), one wave per row.  Each slot minimum belongs to a distinct target, so
+// the k-th smallest slot minimum tS bounds the k-th neighbour: at least k targets have coarse
+// value <= tS, hence true squared distance <= dmax (solved from d <= tS + E(d)).  Every true
+// k-neighbour then has coarse value <= dmax + E(dmax): the slots under that bound are scanned
+// exactly (fp64, reference operation order) and every target with exact distance <= dmax is
+// collected; the k smallest by (distance, index) are written closest first -- the order
+// kdtree.hpp:72-76 returns and icp.hpp:41-51 sums in.  A looser tS (the k-th smallest of the
+// 64 per-lane minima instead of all slot minima) is still a valid bound and is what is used.
+constexpr int kKnnCap = 256; // candidates per row held in LDS; overflow -> exact fallback list
+
+__global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ pts, int m, int k,
+                                                     int row0, int nrows,
+                                                     const float *__restrict__ slotmin, int nslots,
+                                                     const NnFrame *__restrict__ frame,
+                                                     int *__restrict__ knn_idx /*[m][k]*/,
+                                                     int *__restrict__ fb_list, int *__restrict__ fb_count)
+{
+    __shared__ double cand_d[4][kKnnCap];
+    __shared__ int cand_j[4][kKnnCap];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int local = blockIdx.x * 4 + wave;
+    if (local >= nrows) return; // wave-uniform
+    const int i = row0 + local;
+    const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    const float *mine = slotmin + (size_t)local * nslots;
+
+    // per-lane minimum of the slot minima
+    float lmin = kBig;
+    for (int e = lane; e < nslots; e += 64) lmin = __builtin_fminf(lmin, mine[e]);
+    // k-th smallest of the 64 lane minima (ties ordered by lane)
+    int rank = 0;
+#pragma unroll 8
+    for (int L = 0; L < 64; ++L) {
+        const float v = __shfl(lmin, L, 64);
+        rank += (v < lmin || (v == lmin && L < lane)) ? 1 : 0;
+    }
+    const int kk = k < 64 ? k : 64;
+    const unsigned long long who = __ballot(rank == kk - 1);
+    const float tS = __shfl(lmin, __ffsll((long long)who) - 1, 64);
+
+    // bounds (see the header comment of this file for E)
+    const double dx = px - frame->c[0], dy = py - frame->c[1], dz = pz - frame->c[2];
+    const double a = sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + frame->rq;
+    const double u = 5.9604644775390625e-08;
+    const double eps = u * a * (1.0 + 1e-6);
+    const double A = 16.0 * u * a * a;
+    const double ts = tS > 0.f ? (double)tS : 0.0;
+    const double xr = eps + sqrt(eps * eps + (ts + eps * eps + A)); // sqrt(dmax)
+    const double dmax = xr * xr * (1.0 + 1e-9);
+    double tau = dmax + eps * (2.0 * xr + eps) + A;
+    tau = tau * (1.0 + 4e-6) + 1e-300;
+    const float tauf = tS >= kBig ? kBig : __uint_as_float(__float_as_uint((float)tau) + 1u);
+
+    // exact scan of every slot under the bound; keep targets with exact distance <= dmax
+    int total = 0;
+    for (int e0 = 0; e0 < nslots; e0 += 64) {
+        const int e = e0 + lane;
+        const bool flag = e < nslots && mine[e] <= tauf;
+        unsigned long long pend = __ballot(flag);
+        while (pend) {
+            const int L = __ffsll((long long)pend) - 1;
+            pend &= pend - 1;
+            const int se = e0 + L;
+            const int j0 = (se >> 4) * kSplitTargets + (se & 15) * kSlotTargets;
+#pragma unroll
+            for (int o = 0; o < kSlotTargets; o += 64) {
+                const int jj = j0 + o + lane;
+                double d = 1.7976931348623157e308;
+                if (jj < m) d = sqdist(pts[3 * jj], pts[3 * jj + 1], pts[3 * jj + 2], px, py, pz);
+                const bool keep = d <= dmax;
+                const unsigned long long km = __ballot(keep);
+                if (keep) {
+                    const int pos = total + __popcll(km & ((1ull << lane) - 1ull));
+                    if (pos < kKnnCap) {
+                        cand_d[wave][pos] = d;
+                        cand_j[wave][pos] = jj;
+                    }
+                }
+                total += __popcll(km);
+            }
+        }
+    }
+    if (total > kKnnCap) { // too many near-equidistant targets: hand the row to the exact kernel
+        if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = i;
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // rank by (distance, index); the k smallest go out closest first
+    for (int e = lane; e < total; e += 64) {
+        const double d = cand_d[wave][e];
+        const int j = cand_j[wave][e];
+        int r = 0;
+        for (int f = 0; f < total; ++f) {
+            const double df = cand_d[wave][f];
+            const int jf = cand_j[wave][f];
+            r += (df < d || (df == d && jf < j)) ? 1 : 0;
+        }
+        if (r < k) knn_idx[(size_t)i * k + r] = j;
+    }
+}
+
+// exact fp64 k-NN lists, one row per thread (small clouds, and rows the MFMA resolve hands
+// back).  rows: explicit list (list != nullptr, count read from *list_count) or [row0,row1).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_knn_exact_list(const double *__restrict__ pts, int m, int k,
+                                                          int row0, int row1,
+                                                          const int *__restrict__ list,
+                                                          const int *__restrict__ list_count,
+                                                          int *__restrict__ knn_idx)
+{
+    extern __shared__ double knn_smem[];
+    double *ld = knn_smem;
+    int *li = reinterpret_cast<int *>(knn_smem + (size_t)k * BLOCK);
+    const int tid = threadIdx.x;
+    const int nrows = list ? *list_count : row1 - row0;
+    for (int base = blockIdx.x * BLOCK; base < nrows; base += gridDim.x * BLOCK) { // block-uniform
+        const int lr = base + tid;
+        const bool active = lr < nrows;
+        const int i = active ? (list ? list[lr] : row0 + lr) : (list ? list[0] : row0);
+        const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+        int cnt = active ? 0 : k;
+        double thr = active ? __builtin_inf() : -1.0;
+#pragma unroll 4
+        for (int j = 0; j < m; ++j) {
+            const double d = sqdist(pts[3 * j], pts[3 * j + 1], pts[3 * j + 2], px, py, pz);
+            if (d < thr) {
+                int pos = cnt < k ? cnt : k - 1;
+                while (pos > 0) {
+                    const double prev = ld[(pos - 1) * BLOCK + tid];
+                    if (!(prev > d)) break;
+                    ld[pos * BLOCK + tid] = prev;
+                    li[pos * BLOCK + tid] = li[(pos - 1) * BLOCK + tid];
+                    --pos;
+                }
+                ld[pos * BLOCK + tid] = d;
+                li[pos * BLOCK + tid] = j;
+                if (cnt < k) ++cnt;
+                if (cnt == k) thr = ld[(k - 1) * BLOCK + tid];
+            }
+        }
+        if (active)
+            for (int a = 0; a < cnt; ++a) knn_idx[(size_t)i * k + a] = li[a * BLOCK + tid];
+    }
+}
+
+// PCA normal from a closest-first neighbour list (icp.hpp:34-63), one row per thread
+__global__ __launch_bounds__(256) void k_normals_from_knn(const double *__restrict__ pts, int m, int k,
+                                                          int row0, int row1,
+                                                          const int *__restrict__ knn_idx,
+                                                          double *__restrict__ normals)
+{
+    const int i = row0 + blockIdx.x * 256 + threadIdx.x;
+    if (i >= row1) return;
+    const int cnt = k < m ? k : m;
+    const int *nb = knn_idx + (size_t)i * k;
+    double nx = 0.0, ny = 0.0, nz = 1.0; // icp.hpp:34-37
+    if (cnt >= 3) {
+        double cx = 0.0, cy = 0.0, cz = 0.0; // icp.hpp:40-44
+        for (int a = 0; a < cnt; ++a) {
+            const int j = nb[a];
+            cx += pts[3 * j];
+            cy += pts[3 * j + 1];
+            cz += pts[3 * j + 2];
+        }
+        const double kd = (double)cnt;
+        cx /= kd;
+        cy /= kd;
+        cz /= kd;
+        double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0; // icp.hpp:47-52
+        for (int a = 0; a < cnt; ++a) {
+            const int j = nb[a];
+            const double dx = pts[3 * j] - cx, dy = pts[3 * j + 1] - cy, dz = pts[3 * j + 2] - cz;
+            c00 += dx * dx;
+            c01 += dx * dy;
+            c02 += dx * dz;
+            c11 += dy * dy;
+            c12 += dy * dz;
+            c22 += dz * dz;
+        }
+        const double cov[6] = {c00 / kd, c01 / kd, c02 / kd, c11 / kd, c12 / kd, c22 / kd};
+        double v[3];
+        smallest_eigvec_sym3(cov, v); // icp.hpp:55-56
+        if (v[2] < 0.0) {             // icp.hpp:59-61
+            v[0] = -v[0];
+            v[1] = -v[1];
+            v[2] = -v[2];
+        }
+        const double z = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]; // icp.hpp:63
+        if (z > 0.0) {
+            const double sn = __dsqrt_rn(z);
+            v[0] /= sn;
+            v[1] /= sn;
+            v[2] /= sn;
+        }
+        nx = v[0];
+        ny = v[1];
+        nz = v[2];
+    }
+    normals[3 * i] = nx;
+    normals[3 * i + 1] = ny;
+    normals[3 * i + 2] = nz;
 }
 
 } // namespace icpmi

@@ -93,6 +93,27 @@ def test_normals_bit_exact(gpu_ctx, oracle, k):
     assert (got == want).all(axis=1).mean() == 1.0
 
 
+def test_normals_large_bit_exact(gpu_ctx, oracle):
+    """Past the size where the MFMA coarse pass feeds the k-NN resolve."""
+    _, tgt, _ = synth.c3_uniform(20000, seed=14, perm_seed=15)
+    got = gpu_ctx.estimate_normals(tgt, 20)
+    want = oracle.estimate_normals(tgt, None, 20, nthreads=4)
+    assert (got == want).all()
+    _, lid, _ = synth.c2_lidar_pair()
+    assert (gpu_ctx.estimate_normals(lid, 20) == oracle.estimate_normals(lid, None, 20, nthreads=4)).all()
+
+
+def test_normals_candidate_overflow_falls_back_exactly(gpu_ctx, oracle):
+    """300 coincident points: more equidistant candidates than the resolve kernel's LDS
+    list holds, so those rows must go through the exact fallback list -- same bits."""
+    rng = np.random.default_rng(12)
+    pts = np.concatenate([rng.uniform(-20, 20, (8700, 3)), np.tile([[1.5, -2.5, 0.25]], (300, 1))])
+    got = gpu_ctx.estimate_normals(pts, 20)
+    want = oracle.estimate_normals(pts, None, 20, nthreads=4)
+    assert (got == want).all()
+    assert (got[8700:] == [1.0, 0.0, 0.0]).all()  # zero covariance -> first axis
+
+
 def test_normals_few_points(gpu_ctx):
     tgt = np.array([[0.0, 0, 0], [1, 0, 0]])
     assert (gpu_ctx.estimate_normals(tgt, 20) == [[0, 0, 1], [0, 0, 1]]).all()  # icp.hpp:34-37
