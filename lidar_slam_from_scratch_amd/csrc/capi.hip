@@ -229,7 +229,7 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, const double *d_t
     hipLaunchKernelGGL(k_nn_coarse<0>, dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
                        dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const float4 *)ctx->bpack.p, frame,
                        (float2 *)ctx->coarse.p, (float *)nullptr, st);
-    hipLaunchKernelGGL(k_nn_resolve, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_qry, n, d_tgt, m,
+    hipLaunchKernelGGL(k_nn_resolve, dim3((n + 4 * kResolveQ - 1) / (4 * kResolveQ)), dim3(256), 0, ctx->stream, d_qry, n, d_tgt, m,
                        (const float2 *)ctx->coarse.p, splits, frame, d_idx, d_d2, counters, st);
     ctx->prof.nn_pairs += (double)n * (double)m;
     HIP_TRY(ctx, hipGetLastError());

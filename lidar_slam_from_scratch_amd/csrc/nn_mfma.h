@@ -153,7 +153,8 @@ __global__ __launch_bounds__(kCoarseThreads, 4) void k_nn_coarse(
     float *__restrict__ slotmin /*[n][splits*16]*/, const IcpState *__restrict__ st)
 {
     if (st && st->done) return;
-    __shared__ float4 ldsB[32 * 64]; // 32 KiB
+    // 32 KiB of B operands; the 8 KiB tail only serves the epilogue's transpose
+    __shared__ float4 ldsB[32 * 64 + 512];
     const int s = blockIdx.y;
     {
         const float4 *src = Bpack + (size_t)s * (32 * 64);
@@ -176,6 +177,14 @@ __global__ __launch_bounds__(kCoarseThreads, 4) void k_nn_coarse(
             i = i < n ? i : n - 1;
             a[t] = k < 3 ? (float)(qry[3 * i + k] - ck) : 1.0f;
         }
+    }
+    // |P|^2 of the query this lane owns in the epilogue (lane-per-query there)
+    float pn;
+    {
+        const int iq = q0 + lane < n ? q0 + lane : n - 1;
+        const float px = (float)(qry[3 * iq] - c0), py = (float)(qry[3 * iq + 1] - c1),
+                    pz = (float)(qry[3 * iq + 2] - c2);
+        pn = (px * px + py * py) + pz * pz;
     }
     f32x4 m[kCoarseQT];
 #pragma unroll
@@ -200,33 +209,48 @@ __global__ __launch_bounds__(kCoarseThreads, 4) void k_nn_coarse(
         }
     }
 
-    // epilogue: + |P|^2, tag column, 16-lane top-2, one (min, second) pair per query
-    const int g = lane >> 4, col = lane & 15;
+    // epilogue.  Transpose through LDS so that each lane owns ONE query and its 16 column
+    // minima (row stride 20 floats: conflict-free ds_read_b128), then + |P|^2 and either
+    // the tagged (min, second min) pair or the raw 16 values go out, coalesced.
+    __syncthreads(); // every wave is done with the B operands
+    float *sc = reinterpret_cast<float *>(ldsB) + wave * (64 * 20);
+    {
+        const int g = lane >> 4, col = lane & 15;
 #pragma unroll
-    for (int t = 0; t < kCoarseQT; ++t) {
+        for (int t = 0; t < kCoarseQT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int iq = q0 + t * 16 + g * 4 + r;
-            const int ic = iq < n ? iq : n - 1;
-            const float px = (float)(qry[3 * ic] - c0), py = (float)(qry[3 * ic + 1] - c1),
-                        pz = (float)(qry[3 * ic + 2] - c2);
-            const float pn = (px * px + py * py) + pz * pz;
-            const float v = m[t][r] + pn;
-            if (MODE == 1) {
-                if (iq < n) slotmin[(size_t)iq * (gridDim.y * 16) + s * 16 + col] = v;
-                continue;
-            }
-            float v1 = __uint_as_float((__float_as_uint(v) & 0xFFFFFFF0u) | (unsigned)col);
-            float v2 = kBig;
+            for (int r = 0; r < 4; ++r) sc[(t * 16 + g * 4 + r) * 20 + col] = m[t][r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float v[16];
+    {
+        const float4 *rowp = reinterpret_cast<const float4 *>(sc + lane * 20);
 #pragma unroll
-            for (int x = 1; x < 16; x <<= 1) {
-                const float o1 = __shfl_xor(v1, x, 16), o2 = __shfl_xor(v2, x, 16);
-                const float hi = __builtin_fmaxf(v1, o1);
-                v1 = __builtin_fminf(v1, o1);
-                v2 = min3f(hi, v2, o2);
-            }
-            if (col == 0 && iq < n) coarse[(size_t)s * n + iq] = make_float2(v1, v2);
+        for (int e = 0; e < 4; ++e) {
+            const float4 x = rowp[e];
+            v[4 * e] = x.x + pn;
+            v[4 * e + 1] = x.y + pn;
+            v[4 * e + 2] = x.z + pn;
+            v[4 * e + 3] = x.w + pn;
         }
+    }
+    const int iq = q0 + lane;
+    if (MODE == 1) {
+        if (iq < n) {
+            float4 *dst = reinterpret_cast<float4 *>(slotmin + (size_t)iq * (gridDim.y * 16) + s * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
+        }
+    } else {
+        float v1 = kBig, v2 = kBig;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float x = __uint_as_float((__float_as_uint(v[c]) & 0xFFFFFFF0u) | (unsigned)c);
+            const float hi = __builtin_fmaxf(v1, x);
+            v1 = __builtin_fminf(v1, x);
+            v2 = __builtin_fminf(v2, hi);
+        }
+        if (iq < n) coarse[(size_t)s * n + iq] = make_float2(v1, v2);
     }
 }
 
@@ -269,6 +293,12 @@ __device__ __forceinline__ void scan_range(const double *__restrict__ tgt, int m
     }
 }
 
+// One wave resolves 16 queries.  Lane = (query ql = lane&15, quarter = lane>>4): the four
+// quarters share the bookkeeping of a query (each scans a quarter of the splits) and each
+// quarter-wave scans one winning slot at a time, 8 consecutive targets (192 contiguous
+// bytes) per lane, so 4 slots are in flight per wave and ~6 waves per SIMD hide the latency.
+constexpr int kResolveQ = 16;
+
 __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ qry, int n,
                                                     const double *__restrict__ tgt, int m,
                                                     const float2 *__restrict__ coarse, int splits,
@@ -279,38 +309,71 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
 {
     if (st && st->done) return;
     const int lane = threadIdx.x & 63;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int i = wave_global * 64 + lane; // lane-per-query for the bookkeeping phases
+    const int ql = lane & 15, quarter = lane >> 4;
+    const int qbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kResolveQ;
+    if (qbase >= n) return; // wave-uniform
+    const int i = qbase + ql;
     const bool valid = i < n;
     const int ic = valid ? i : n - 1;
     const double px = qry[3 * ic], py = qry[3 * ic + 1], pz = qry[3 * ic + 2];
 
-    // phase 1: smallest coarse value over the splits
+    // phase 1: smallest coarse value over the splits (each quarter takes every 4th split)
     float best = kBig;
     int bs = 0;
-    for (int s = 0; s < splits; ++s) {
+    for (int s = quarter; s < splits; s += 4) {
         const float v = coarse[(size_t)s * n + ic].x;
         if (v < best) {
             best = v;
             bs = s;
         }
     }
+#pragma unroll
+    for (int x = 16; x < 64; x <<= 1) {
+        const float ov = __shfl_xor(best, x, 64);
+        const int os = __shfl_xor(bs, x, 64);
+        if (ov < best || (ov == best && os < bs)) {
+            best = ov;
+            bs = os;
+        }
+    }
     const int bcol = (int)(__float_as_uint(best) & 15u);
 
-    // phase 2: exact evaluation of each query's winning slot (wave-cooperative)
+    // phase 2: exact evaluation of the winning slots, one query per quarter-wave and round
     double bd = 1.7976931348623157e308;
     int bj = 0x7fffffff;
-    const unsigned long long vmask = __ballot(valid);
-    for (int L = 0; L < 64; ++L) {
-        if (!((vmask >> L) & 1ull)) continue; // wave-uniform
-        const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
-        const int s = __shfl(bs, L, 64), c = __shfl(bcol, L, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int src = quarter * 4 + r; // the query this quarter scans now (a lane of quarter 0)
+        const double qx = __shfl(px, src, 64), qy = __shfl(py, src, 64), qz = __shfl(pz, src, 64);
+        const int s = __shfl(bs, src, 64), c = __shfl(bcol, src, 64);
+        const int j0 = s * kSplitTargets + c * kSlotTargets + ql * 8;
         double d = 1.7976931348623157e308;
         int j = 0x7fffffff;
-        scan_range(tgt, m, s * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
-        if (lane == L) {
-            bd = d;
-            bj = j;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int jj = j0 + o;
+            const int jc = jj < m ? jj : m - 1;
+            const double dd = sqdist(tgt[3 * jc], tgt[3 * jc + 1], tgt[3 * jc + 2], qx, qy, qz);
+            if (jj < m && dd < d) {
+                d = dd;
+                j = jj;
+            }
+        }
+#pragma unroll
+        for (int x = 1; x < 16; x <<= 1) {
+            const double od = __shfl_xor(d, x, 64);
+            const int oj = __shfl_xor(j, x, 64);
+            if (od < d || (od == d && oj < j)) {
+                d = od;
+                j = oj;
+            }
+        }
+        // query ql was scanned by quarter ql>>2 in round ql&3
+        const double rd = __shfl(d, (ql >> 2) * 16, 64);
+        const int rj = __shfl(j, (ql >> 2) * 16, 64);
+        if ((ql & 3) == r) {
+            bd = rd;
+            bj = rj;
         }
     }
 
@@ -325,32 +388,37 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
     const float tauf = __uint_as_float(__float_as_uint((float)tau) + 1u);
 
     unsigned extra_slots = 0, extra_splits = 0;
-    for (int s = 0; s < splits; ++s) {
-        const float2 v = coarse[(size_t)s * n + ic];
-        const bool whole = valid && v.y <= tauf;               // a second column is inside the bound
+    for (int s0 = 0; s0 < splits; s0 += 4) {
+        const int s = s0 + quarter;
+        float2 v = make_float2(kBig, kBig);
+        if (s < splits) v = coarse[(size_t)s * n + ic];
+        const bool whole = valid && v.y <= tauf;            // a second column is inside the bound
         const bool slot = valid && !whole && s != bs && v.x <= tauf;
         unsigned long long pend = __ballot(whole || slot);
-        while (pend) {                                         // rare; wave-uniform loop
+        while (pend) {                                      // rare; wave-uniform loop
             const int L = __ffsll((long long)pend) - 1;
             pend &= pend - 1;
             const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
             const int w = __shfl((int)whole, L, 64);
             const int c = __shfl((int)(__float_as_uint(v.x) & 15u), L, 64);
+            const int sL = s0 + (L >> 4);
             double d = 1.7976931348623157e308;
             int j = 0x7fffffff;
-            if (w) scan_range(tgt, m, s * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
-            else scan_range(tgt, m, s * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
-            if (lane == L) {
+            if (w) scan_range(tgt, m, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
+            else scan_range(tgt, m, sL * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
+            if (ql == (L & 15)) { // every replica of that query takes the result
                 if (d < bd || (d == bd && j < bj)) {
                     bd = d;
                     bj = j;
                 }
+            }
+            if (lane == L) {
                 if (w) ++extra_splits;
                 else ++extra_slots;
             }
         }
     }
-    if (valid) {
+    if (valid && quarter == 0) {
         idx[i] = bj;
         if (d2out) d2out[i] = bd;
     }
