@@ -226,7 +226,7 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, const double *d_t
     const NnFrame *frame = (const NnFrame *)ctx->nn_misc.p;
     unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);
     StageTimer t(ctx, ST_NN);
-    hipLaunchKernelGGL(k_nn_coarse<0>, dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
+    hipLaunchKernelGGL((k_nn_coarse<0, kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
                        dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const float4 *)ctx->bpack.p, frame,
                        (float2 *)ctx->coarse.p, (float *)nullptr, st);
     hipLaunchKernelGGL(k_nn_resolve, dim3((n + 4 * kResolveQ - 1) / (4 * kResolveQ)), dim3(256), 0, ctx->stream, d_qry, n, d_tgt, m,
@@ -295,7 +295,7 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
         const NnFrame *frame = (const NnFrame *)ctx->nn_misc.p;
         for (long c0 = row0; c0 < row1; c0 += chunk) {
             const int nq = (int)std::min<long>(chunk, row1 - c0);
-            hipLaunchKernelGGL(k_nn_coarse<1>, dim3((nq + kCoarseQueries - 1) / kCoarseQueries, splits),
+            hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves>), dim3((nq + kCoarseQueries - 1) / kCoarseQueries, splits),
                                dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const float4 *)ctx->bpack.p,
                                frame, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
             hipLaunchKernelGGL(k_knn_resolve, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, m, k, (int)c0, nq,

@@ -43,8 +43,9 @@ constexpr int kSplitTiles = 128;                  // target tiles (16 targets ea
 constexpr int kSplitTargets = kSplitTiles * 16;   // 2048
 constexpr int kSlotTargets = kSplitTiles;         // targets per (split, column) slot
 constexpr int kCoarseQT = 4;                      // query tiles per wave
-constexpr int kCoarseThreads = 512;               // 8 waves
-constexpr int kCoarseQueries = 16 * kCoarseQT * (kCoarseThreads / 64); // 512 per workgroup
+constexpr int kCoarseWaves = 8;                   // waves per workgroup
+constexpr int kCoarseThreads = 64 * kCoarseWaves;
+constexpr int kCoarseQueries = 16 * kCoarseQT * kCoarseWaves; // queries per workgroup
 constexpr float kBig = 3.0e38f;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -146,49 +147,53 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
 
 // MODE 0: 1-NN epilogue -> coarse[split][n] = (tagged min, second min over columns)
 // MODE 1: k-NN epilogue  -> slotmin[query][split*16 + column], every column minimum kept
-template <int MODE>
-__global__ __launch_bounds__(kCoarseThreads, 4) void k_nn_coarse(
+// QT = query tiles (16 queries) per wave, a multiple of 4; WAVES = waves per workgroup.
+template <int MODE, int QT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     const double *__restrict__ qry, int n, const float4 *__restrict__ Bpack,
     const NnFrame *__restrict__ frame, float2 *__restrict__ coarse /*[split][n]*/,
     float *__restrict__ slotmin /*[n][splits*16]*/, const IcpState *__restrict__ st)
 {
+    static_assert(QT % 4 == 0, "epilogue works on groups of 64 queries");
+    constexpr int THREADS = 64 * WAVES;
+    constexpr int SCRATCH4 = WAVES * 64 * 20 / 4 > 32 * 64 ? WAVES * 64 * 20 / 4 : 32 * 64;
     if (st && st->done) return;
-    // 32 KiB of B operands; the 8 KiB tail only serves the epilogue's transpose
-    __shared__ float4 ldsB[32 * 64 + 512];
+    // 32 KiB of B operands; reused (plus a tail) for the epilogue's transpose
+    __shared__ float4 ldsB[SCRATCH4];
     const int s = blockIdx.y;
     {
         const float4 *src = Bpack + (size_t)s * (32 * 64);
 #pragma unroll
-        for (int e = 0; e < (32 * 64) / kCoarseThreads; ++e)
-            ldsB[threadIdx.x + e * kCoarseThreads] = src[threadIdx.x + e * kCoarseThreads];
+        for (int e = 0; e < (32 * 64) / THREADS; ++e) ldsB[threadIdx.x + e * THREADS] = src[threadIdx.x + e * THREADS];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q0 = blockIdx.x * kCoarseQueries + wave * (16 * kCoarseQT);
+    const int q0 = (blockIdx.x * WAVES + wave) * (16 * QT);
     const double c0 = frame->c[0], c1 = frame->c[1], c2 = frame->c[2];
 
     // A operands: lane l holds component k = l>>4 of query row l&15; k == 3 is the constant 1
-    float a[kCoarseQT];
+    float a[QT];
     {
         const int row = lane & 15, k = lane >> 4;
         const double ck = k == 0 ? c0 : (k == 1 ? c1 : c2);
 #pragma unroll
-        for (int t = 0; t < kCoarseQT; ++t) {
+        for (int t = 0; t < QT; ++t) {
             int i = q0 + t * 16 + row;
             i = i < n ? i : n - 1;
             a[t] = k < 3 ? (float)(qry[3 * i + k] - ck) : 1.0f;
         }
     }
-    // |P|^2 of the query this lane owns in the epilogue (lane-per-query there)
-    float pn;
-    {
-        const int iq = q0 + lane < n ? q0 + lane : n - 1;
+    // |P|^2 of the queries this lane owns in the epilogue (lane-per-query there)
+    float pn[QT / 4];
+#pragma unroll
+    for (int gq = 0; gq < QT / 4; ++gq) {
+        const int iq = q0 + gq * 64 + lane < n ? q0 + gq * 64 + lane : n - 1;
         const float px = (float)(qry[3 * iq] - c0), py = (float)(qry[3 * iq + 1] - c1),
                     pz = (float)(qry[3 * iq + 2] - c2);
-        pn = (px * px + py * py) + pz * pz;
+        pn[gq] = (px * px + py * py) + pz * pz;
     }
-    f32x4 m[kCoarseQT];
+    f32x4 m[QT];
 #pragma unroll
-    for (int t = 0; t < kCoarseQT; ++t) m[t] = (f32x4){kBig, kBig, kBig, kBig};
+    for (int t = 0; t < QT; ++t) m[t] = (f32x4){kBig, kBig, kBig, kBig};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(kCoarseThreads, 4) void k_nn_coarse(
     for (int t4 = 0; t4 < 32; ++t4) {
         const float4 b = ldsB[t4 * 64 + lane];
 #pragma unroll
-        for (int t = 0; t < kCoarseQT; ++t) {
+        for (int t = 0; t < QT; ++t) {
             const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.x, zero, 0, 0, 0);
             const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.y, zero, 0, 0, 0);
             const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.z, zero, 0, 0, 0);
@@ -209,48 +214,51 @@ __global__ __launch_bounds__(kCoarseThreads, 4) void k_nn_coarse(
         }
     }
 
-    // epilogue.  Transpose through LDS so that each lane owns ONE query and its 16 column
-    // minima (row stride 20 floats: conflict-free ds_read_b128), then + |P|^2 and either
-    // the tagged (min, second min) pair or the raw 16 values go out, coalesced.
+    // epilogue.  Transpose through LDS, 64 queries at a time, so that each lane owns ONE
+    // query and its 16 column minima (row stride 20 floats: conflict-free ds_read_b128),
+    // then + |P|^2 and either the tagged (min, second min) pair or the raw 16 values go
+    // out, coalesced.
     __syncthreads(); // every wave is done with the B operands
     float *sc = reinterpret_cast<float *>(ldsB) + wave * (64 * 20);
-    {
-        const int g = lane >> 4, col = lane & 15;
+    const int g = lane >> 4, col = lane & 15;
 #pragma unroll
-        for (int t = 0; t < kCoarseQT; ++t)
+    for (int gq = 0; gq < QT / 4; ++gq) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc[(t * 16 + g * 4 + r) * 20 + col] = m[t][r];
-    }
-    __builtin_amdgcn_wave_barrier();
-    float v[16];
-    {
-        const float4 *rowp = reinterpret_cast<const float4 *>(sc + lane * 20);
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float4 x = rowp[e];
-            v[4 * e] = x.x + pn;
-            v[4 * e + 1] = x.y + pn;
-            v[4 * e + 2] = x.z + pn;
-            v[4 * e + 3] = x.w + pn;
+            for (int r = 0; r < 4; ++r) sc[(t * 16 + g * 4 + r) * 20 + col] = m[gq * 4 + t][r];
+        __builtin_amdgcn_wave_barrier();
+        float v[16];
+        {
+            const float4 *rowp = reinterpret_cast<const float4 *>(sc + lane * 20);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 x = rowp[e];
+                v[4 * e] = x.x + pn[gq];
+                v[4 * e + 1] = x.y + pn[gq];
+                v[4 * e + 2] = x.z + pn[gq];
+                v[4 * e + 3] = x.w + pn[gq];
+            }
         }
-    }
-    const int iq = q0 + lane;
-    if (MODE == 1) {
-        if (iq < n) {
-            float4 *dst = reinterpret_cast<float4 *>(slotmin + (size_t)iq * (gridDim.y * 16) + s * 16);
+        __builtin_amdgcn_wave_barrier();
+        const int iq = q0 + gq * 64 + lane;
+        if (MODE == 1) {
+            if (iq < n) {
+                float4 *dst = reinterpret_cast<float4 *>(slotmin + (size_t)iq * (gridDim.y * 16) + s * 16);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
-        }
-    } else {
-        float v1 = kBig, v2 = kBig;
+                for (int e = 0; e < 4; ++e) dst[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
+            }
+        } else {
+            float v1 = kBig, v2 = kBig;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float x = __uint_as_float((__float_as_uint(v[c]) & 0xFFFFFFF0u) | (unsigned)c);
-            const float hi = __builtin_fmaxf(v1, x);
-            v1 = __builtin_fminf(v1, x);
-            v2 = __builtin_fminf(v2, hi);
+            for (int c = 0; c < 16; ++c) {
+                const float x = __uint_as_float((__float_as_uint(v[c]) & 0xFFFFFFF0u) | (unsigned)c);
+                const float hi = __builtin_fmaxf(v1, x);
+                v1 = __builtin_fminf(v1, x);
+                v2 = __builtin_fminf(v2, hi);
+            }
+            if (iq < n) coarse[(size_t)s * n + iq] = make_float2(v1, v2);
         }
-        if (iq < n) coarse[(size_t)s * n + iq] = make_float2(v1, v2);
     }
 }
 
