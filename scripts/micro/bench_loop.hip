@@ -1,0 +1,171 @@
+// Micro-benchmark: scheduling variants of the coarse inner loop (tuning aid only).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "nn_mfma.h"
+using namespace icpmi;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+template <int VAR, int QT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_loop(const float4 *__restrict__ Bpack, float *out, int nevertrue)
+{
+    constexpr int THREADS = 64 * WAVES;
+    __shared__ float4 ldsB[32 * 64];
+    const int s = blockIdx.y;
+    for (int e = 0; e < (32 * 64) / THREADS; ++e) ldsB[threadIdx.x + e * THREADS] = Bpack[(size_t)s * 2048 + threadIdx.x + e * THREADS];
+    const int lane = threadIdx.x & 63;
+    float a[QT];
+    for (int t = 0; t < QT; ++t) a[t] = (float)(lane + t) * 0.01f;
+    f32x4 m[QT];
+    for (int t = 0; t < QT; ++t) m[t] = (f32x4){kBig, kBig, kBig, kBig};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    float keep = 0.f;
+    if (VAR == 0) {
+#pragma unroll 2
+        for (int t4 = 0; t4 < 32; ++t4) {
+            const float4 b = ldsB[t4 * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.x, zero, 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.y, zero, 0, 0, 0);
+                const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.z, zero, 0, 0, 0);
+                const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.w, zero, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    m[t][r] = min3f(m[t][r], d0[r], d1[r]);
+                    m[t][r] = min3f(m[t][r], d2[r], d3[r]);
+                }
+            }
+        }
+    } else if (VAR == 1) { // VALU work independent of the MFMA results
+        float x = a[0], y = a[1];
+#pragma unroll 2
+        for (int t4 = 0; t4 < 32; ++t4) {
+            const float4 b = ldsB[t4 * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.x, zero, 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.y, zero, 0, 0, 0);
+                const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.z, zero, 0, 0, 0);
+                const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.w, zero, 0, 0, 0);
+                asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    m[t][r] = min3f(m[t][r], x, y);
+                    asm volatile("" : "+v"(m[t][r]));
+                    m[t][r] = min3f(m[t][r], y, x);
+                    asm volatile("" : "+v"(m[t][r]));
+                }
+            }
+        }
+    } else if (VAR == 2) { // consume the previous query tile's results (one-stage software pipeline)
+        f32x4 p0 = zero, p1 = zero, p2 = zero, p3 = zero;
+        int pt = 0;
+#pragma unroll 1
+        for (int t4 = 0; t4 < 32; ++t4) {
+            const float4 b = ldsB[t4 * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.x, zero, 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.y, zero, 0, 0, 0);
+                const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.z, zero, 0, 0, 0);
+                const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.w, zero, 0, 0, 0);
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int tp = (t + QT - 1) % QT; // tile whose results p* hold
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    m[tp][r] = min3f(m[tp][r], p0[r], p1[r]);
+                    m[tp][r] = min3f(m[tp][r], p2[r], p3[r]);
+                }
+                // interleave: MFMA, 2 VALU, MFMA, 2 VALU ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                p0 = d0; p1 = d1; p2 = d2; p3 = d3;
+            }
+        }
+        (void)pt;
+        // drain (first-iteration garbage min with zero is harmless for timing)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[QT - 1][r] = min3f(m[QT - 1][r], p0[r], p1[r]);
+    } else if (VAR == 3) { // min (2-input) instead of min3
+#pragma unroll 2
+        for (int t4 = 0; t4 < 32; ++t4) {
+            const float4 b = ldsB[t4 * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.x, zero, 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.y, zero, 0, 0, 0);
+                const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.z, zero, 0, 0, 0);
+                const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.w, zero, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    m[t][r] = __builtin_fminf(m[t][r], d0[r]);
+                    m[t][r] = __builtin_fminf(m[t][r], d1[r]);
+                    m[t][r] = __builtin_fminf(m[t][r], d2[r]);
+                    m[t][r] = __builtin_fminf(m[t][r], d3[r]);
+                }
+            }
+        }
+    } else if (VAR == 4) { // only half the VALU work (1 min3 per MFMA): is the cost per VALU op?
+#pragma unroll 2
+        for (int t4 = 0; t4 < 32; ++t4) {
+            const float4 b = ldsB[t4 * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.x, zero, 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.y, zero, 0, 0, 0);
+                const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.z, zero, 0, 0, 0);
+                const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.w, zero, 0, 0, 0);
+                asm volatile("" ::"v"(d2), "v"(d3));
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    m[t][r] = min3f(m[t][r], d0[r], d1[r]);
+                    m[t][r + 2] = min3f(m[t][r + 2], d0[r + 2], d1[r + 2]);
+                }
+            }
+        }
+    }
+    float acc = keep;
+    for (int t = 0; t < QT; ++t) for (int r = 0; r < 4; ++r) acc += m[t][r];
+    if (acc == (float)nevertrue) out[threadIdx.x] = acc;
+}
+
+template <typename F>
+static float timeit(F f, int reps = 10)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGetLastError());
+    return ms / reps;
+}
+
+int main()
+{
+    const int n = 100000, m = 100000;
+    const int splits = (m + kSplitTargets - 1) / kSplitTargets;
+    float4 *bp; float *out;
+    CK(hipMalloc(&bp, (size_t)splits * 2048 * 16)); CK(hipMalloc(&out, 4096));
+    std::vector<float> h((size_t)splits * 2048 * 4);
+    srand(2);
+    for (auto &v : h) v = -50 + 100.0f * rand() / RAND_MAX;
+    CK(hipMemcpy(bp, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    const double ideal_ms = (double)n * m / 256.0 * 32.0 / 1024.0 / 2.4e9 * 1e3;
+#define RUN(VAR, QT, W) { const int qpb = 16 * QT * W; float ms = timeit([&] { hipLaunchKernelGGL((k_loop<VAR, QT, W>), dim3((n + qpb - 1) / qpb, splits), dim3(64 * W), 0, 0, bp, out, -12345); }); printf("var %d QT=%d W=%d : %.3f ms  (%.1f%%)\n", VAR, QT, W, ms, 100 * ideal_ms / ms); }
+    RUN(0, 4, 8) RUN(1, 4, 8) RUN(2, 4, 8) RUN(3, 4, 8) RUN(4, 4, 8)
+    RUN(0, 8, 8) RUN(1, 8, 8) RUN(2, 8, 8) RUN(2, 8, 4) RUN(2, 4, 4)
+    return 0;
+}
