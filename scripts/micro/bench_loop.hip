@@ -134,6 +134,54 @@ __global__ __launch_bounds__(64 * WAVES) void k_loop(const float4 *__restrict__ 
             }
         }
     }
+    else if (VAR == 5) { // integer min on the float bits (C = |P|^2 keeps results >= 0)
+        f32x4 cinit[QT];
+        for (int t = 0; t < QT; ++t) cinit[t] = (f32x4){5000.f + lane, 5001.f, 5002.f, 5003.f};
+        int mi[QT][4];
+        for (int t = 0; t < QT; ++t) for (int r = 0; r < 4; ++r) mi[t][r] = 0x7f000000;
+#pragma unroll 2
+        for (int t4 = 0; t4 < 32; ++t4) {
+            const float4 b = ldsB[t4 * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.x, cinit[t], 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.y, cinit[t], 0, 0, 0);
+                const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.z, cinit[t], 0, 0, 0);
+                const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.w, cinit[t], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mi[t][r] = min(min(mi[t][r], __float_as_int(d0[r])), __float_as_int(d1[r]));
+                    mi[t][r] = min(min(mi[t][r], __float_as_int(d2[r])), __float_as_int(d3[r]));
+                }
+            }
+        }
+        for (int t = 0; t < QT; ++t) for (int r = 0; r < 4; ++r) m[t][r] = __int_as_float(mi[t][r]);
+    } else if (VAR == 6 || VAR == 7) { // bf16 16x16x32 MFMA (one per 16x16 tile), float (6) or int (7) min
+        typedef short bf16x8 __attribute__((ext_vector_type(8)));
+        bf16x8 ab[QT];
+        for (int t = 0; t < QT; ++t) for (int e = 0; e < 8; ++e) ab[t][e] = (short)(0x3f80 + lane + t + e);
+        f32x4 cinit[QT];
+        for (int t = 0; t < QT; ++t) cinit[t] = (f32x4){5000.f + lane, 5001.f, 5002.f, 5003.f};
+        int mi[QT][4];
+        for (int t = 0; t < QT; ++t) for (int r = 0; r < 4; ++r) mi[t][r] = 0x7f000000;
+        const bf16x8 *ldsH = reinterpret_cast<const bf16x8 *>(ldsB);
+#pragma unroll 2
+        for (int tt = 0; tt < 128; tt += 2) {
+            const bf16x8 b0 = ldsH[(tt & 31) * 64 + lane];
+            const bf16x8 b1 = ldsH[((tt + 1) & 31) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[t], b0, cinit[t], 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[t], b1, cinit[t], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (VAR == 6) m[t][r] = min3f(m[t][r], d0[r], d1[r]);
+                    else mi[t][r] = min(min(mi[t][r], __float_as_int(d0[r])), __float_as_int(d1[r]));
+                }
+            }
+        }
+        if (VAR == 7) for (int t = 0; t < QT; ++t) for (int r = 0; r < 4; ++r) m[t][r] = __int_as_float(mi[t][r]);
+    }
     float acc = keep;
     for (int t = 0; t < QT; ++t) for (int r = 0; r < 4; ++r) acc += m[t][r];
     if (acc == (float)nevertrue) out[threadIdx.x] = acc;
@@ -161,11 +209,10 @@ int main()
     CK(hipMalloc(&bp, (size_t)splits * 2048 * 16)); CK(hipMalloc(&out, 4096));
     std::vector<float> h((size_t)splits * 2048 * 4);
     srand(2);
-    for (auto &v : h) v = -50 + 100.0f * rand() / RAND_MAX;
+    for (auto &v : h) v = -50 + 100.0f * (float)(rand() % 100000) / 100000.0f;
     CK(hipMemcpy(bp, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     const double ideal_ms = (double)n * m / 256.0 * 32.0 / 1024.0 / 2.4e9 * 1e3;
 #define RUN(VAR, QT, W) { const int qpb = 16 * QT * W; float ms = timeit([&] { hipLaunchKernelGGL((k_loop<VAR, QT, W>), dim3((n + qpb - 1) / qpb, splits), dim3(64 * W), 0, 0, bp, out, -12345); }); printf("var %d QT=%d W=%d : %.3f ms  (%.1f%%)\n", VAR, QT, W, ms, 100 * ideal_ms / ms); }
-    RUN(0, 4, 8) RUN(1, 4, 8) RUN(2, 4, 8) RUN(3, 4, 8) RUN(4, 4, 8)
-    RUN(0, 8, 8) RUN(1, 8, 8) RUN(2, 8, 8) RUN(2, 8, 4) RUN(2, 4, 4)
+    RUN(0, 4, 8) RUN(5, 4, 8) RUN(6, 4, 8) RUN(7, 4, 8) RUN(6, 8, 8) RUN(7, 8, 8) RUN(6, 4, 4) RUN(6, 8, 4) RUN(6, 2, 8)
     return 0;
 }
