@@ -141,7 +141,7 @@ def main():
                        "source_points": int(src.shape[0]), "target_points": int(m),
                        "parallelism": "source sharded x%d, 29-double RCCL all-reduce/iter" % world
                        if world > 1 else "single GPU",
-                       "search": {0: "auto", 1: "exact_f64", 2: "mfma_f32+f64 recheck"}[args.search]},
+                       "search": {0: "auto", 1: "exact_f64", 2: "mfma_bf16x3+f64 resolve"}[args.search]},
             "steady_state_it_per_s": args.steps / (prof["loop_ms"] * 1e-3) * (args.steps + 1) / args.steps
             if prof["loop_ms"] > 0 else None,
             "stage_ms": {k: prof[k] for k in ("nn_ms", "reduce_ms", "transform_ms", "normals_ms",

@@ -42,7 +42,7 @@ extern "C" {
 /* nearest-neighbour search engines (all return the exact fp64 nearest neighbour) */
 #define ICPMI_SEARCH_AUTO 0
 #define ICPMI_SEARCH_EXACT_F64 1     /* fp64 brute force, SGPR-broadcast targets */
-#define ICPMI_SEARCH_MFMA_F32 2      /* fp32 MFMA coarse pass + certified fp64 recheck */
+#define ICPMI_SEARCH_MFMA_BF16 2     /* bf16x3 MFMA coarse pass over all pairs + certified fp64 resolve */
 
 typedef struct icpmi_ctx icpmi_ctx;
 
@@ -81,6 +81,7 @@ typedef struct {
     double normals_ms;   int64_t normals_launches;   /* k-NN + PCA */
     double total_ms;     int64_t calls;              /* whole icpmi_align* calls, device time */
     double loop_ms;                                  /* iteration loop + post-loop pass only */
+    double setup_ms;                                 /* Morton sort + operand packing of the target */
     double nn_pairs;                                 /* (source,target) pairs evaluated by nn passes */
     int64_t nn_recheck_queries;                      /* queries re-resolved in fp64 (MFMA engine) */
     int64_t nn_fallback_queries;                     /* queries sent to the fp64 exhaustive fallback */

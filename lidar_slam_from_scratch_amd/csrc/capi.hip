@@ -25,6 +25,11 @@
 
 using namespace icpmi;
 
+namespace icpmi {
+hipError_t sort_pairs_u32(void *temp, size_t *temp_bytes, const unsigned *keys_in, unsigned *keys_out,
+                          const unsigned *vals_in, unsigned *vals_out, unsigned n, hipStream_t stream);
+}
+
 namespace {
 
 std::string g_create_error;
@@ -39,7 +44,7 @@ struct EventPair {
     int stage;
 };
 
-enum Stage { ST_NN = 0, ST_REDUCE = 1, ST_TRANSFORM = 2, ST_NORMALS = 3, ST_TOTAL = 4, ST_LOOP = 5 };
+enum Stage { ST_NN = 0, ST_REDUCE = 1, ST_TRANSFORM = 2, ST_NORMALS = 3, ST_TOTAL = 4, ST_LOOP = 5, ST_SETUP = 6 };
 
 struct Rccl {
     void *lib = nullptr;
@@ -61,6 +66,7 @@ struct icpmi_ctx {
 
     DevBuf cur, nrm, idx, part_d2, part_idx, partials, history, stage_a, stage_b, stage_c, d2out;
     DevBuf knn_idx, slotmin, fb_list;         // k-NN lists, slot minima, rows for the exact fallback
+    DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
     int nn_splits = 0;
@@ -161,7 +167,7 @@ struct StageTimer {
 // call after the stream has been synchronised
 void harvest_profile(icpmi_ctx *ctx)
 {
-    if (ctx->opt.profile && ctx->nn_engine == ICPMI_SEARCH_MFMA_F32 && ctx->nn_misc.p) {
+    if (ctx->opt.profile && ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && ctx->nn_misc.p) {
         unsigned long long cnt[2] = {0, 0};
         if (hipMemcpy(cnt, (char *)ctx->nn_misc.p + 128, sizeof(cnt), hipMemcpyDeviceToHost) == hipSuccess) {
             ctx->prof.nn_recheck_queries += (int64_t)cnt[0];
@@ -180,6 +186,7 @@ void harvest_profile(icpmi_ctx *ctx)
         case ST_NORMALS: ctx->prof.normals_ms += ms; ctx->prof.normals_launches++; break;
         case ST_TOTAL: ctx->prof.total_ms += ms; ctx->prof.calls++; break;
         case ST_LOOP: ctx->prof.loop_ms += ms; break;
+        case ST_SETUP: ctx->prof.setup_ms += ms; break;
         default: break;
         }
     }
@@ -190,47 +197,65 @@ void harvest_profile(icpmi_ctx *ctx)
 
 // Choose and prepare the search engine for a target cloud (once per call: the target does
 // not move).  Both engines return the same indices; AUTO takes the MFMA engine once the
-// pair count makes its fixed costs (bounding box, operand packing, resolve) worthwhile.
+// pair count makes its fixed costs (Morton sort, operand packing, resolve) worthwhile.
 int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
 {
     int engine = ctx->opt.search;
     if (engine == ICPMI_SEARCH_AUTO)
-        engine = (m >= 2 * kSplitTargets && n_hint >= 1024) ? ICPMI_SEARCH_MFMA_F32 : ICPMI_SEARCH_EXACT_F64;
+        engine = (m >= 4 * kSplitTargets && n_hint >= 1024) ? ICPMI_SEARCH_MFMA_BF16 : ICPMI_SEARCH_EXACT_F64;
     ctx->nn_engine = engine;
-    if (engine != ICPMI_SEARCH_MFMA_F32) return ICPMI_OK;
+    if (engine != ICPMI_SEARCH_MFMA_BF16) return ICPMI_OK;
     const int splits = (m + kSplitTargets - 1) / kSplitTargets;
     ctx->nn_splits = splits;
     int rc;
     const int bblocks = std::max(1, std::min(256, (m + 255) / 256));
-    if ((rc = reserve(ctx, ctx->bpack, sizeof(float4) * 32 * 64 * (size_t)splits))) return rc;
+    size_t sort_bytes = 0;
+    HIP_TRY(ctx, sort_pairs_u32(nullptr, &sort_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned)m, ctx->stream));
+    if ((rc = reserve(ctx, ctx->bpack, sizeof(uint4) * kSplitTiles * 64 * (size_t)splits))) return rc;
     if ((rc = reserve(ctx, ctx->bbox_part, sizeof(double) * 6 * (size_t)bblocks))) return rc;
     if ((rc = reserve(ctx, ctx->nn_misc, 256))) return rc;
+    if ((rc = reserve(ctx, ctx->sort_keys, sizeof(unsigned) * 4 * (size_t)m))) return rc;
+    if ((rc = reserve(ctx, ctx->sort_tmp, sort_bytes))) return rc;
+    if ((rc = reserve(ctx, ctx->tgt_sorted, sizeof(double) * 3 * (size_t)m))) return rc;
+    if ((rc = reserve(ctx, ctx->frames, sizeof(SplitFrame) * (size_t)splits))) return rc;
     NnFrame *frame = (NnFrame *)ctx->nn_misc.p;
+    unsigned *keys_in = (unsigned *)ctx->sort_keys.p, *keys_out = keys_in + m, *vals_in = keys_in + 2 * (size_t)m,
+             *perm = keys_in + 3 * (size_t)m;
     hipStream_t s = ctx->stream;
-    StageTimer t(ctx, ST_NORMALS + 100); // setup: not attributed to a stage
+    StageTimer t(ctx, ST_SETUP);
     hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_tgt, m, (double *)ctx->bbox_part.p);
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, frame);
-    hipLaunchKernelGGL(k_pack_targets, dim3((splits * 32 * 64 + 255) / 256), dim3(256), 0, s, d_tgt, m,
-                       (const NnFrame *)frame, (float4 *)ctx->bpack.p, splits);
+    hipLaunchKernelGGL(k_morton_keys, dim3((m + 255) / 256), dim3(256), 0, s, d_tgt, m, (const NnFrame *)frame,
+                       keys_in, vals_in);
+    HIP_TRY(ctx, sort_pairs_u32(ctx->sort_tmp.p, &sort_bytes, keys_in, keys_out, vals_in, perm, (unsigned)m, s));
+    hipLaunchKernelGGL(k_gather_points, dim3((m + 255) / 256), dim3(256), 0, s, d_tgt, (const unsigned *)perm, m,
+                       (double *)ctx->tgt_sorted.p);
+    hipLaunchKernelGGL(k_split_frames, dim3(splits), dim3(256), 0, s, (const double *)ctx->tgt_sorted.p, m,
+                       (SplitFrame *)ctx->frames.p);
+    hipLaunchKernelGGL(k_pack_targets, dim3((splits * kSplitTiles * 64 + 255) / 256), dim3(256), 0, s,
+                       (const double *)ctx->tgt_sorted.p, m, (const SplitFrame *)ctx->frames.p,
+                       (uint4 *)ctx->bpack.p, splits);
     HIP_TRY(ctx, hipMemsetAsync((char *)ctx->nn_misc.p + 128, 0, 16, s));
     HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;
 }
 
-int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, const double *d_tgt, int m, int *d_idx,
-                   double *d_d2, const IcpState *st)
+int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx, double *d_d2,
+                   const IcpState *st)
 {
     const int splits = ctx->nn_splits;
     int rc;
     if ((rc = reserve(ctx, ctx->coarse, sizeof(float2) * (size_t)splits * n))) return rc;
-    const NnFrame *frame = (const NnFrame *)ctx->nn_misc.p;
+    const SplitFrame *frames = (const SplitFrame *)ctx->frames.p;
+    const unsigned *perm = (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m;
     unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);
     StageTimer t(ctx, ST_NN);
     hipLaunchKernelGGL((k_nn_coarse<0, kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
-                       dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const float4 *)ctx->bpack.p, frame,
+                       dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,
                        (float2 *)ctx->coarse.p, (float *)nullptr, st);
-    hipLaunchKernelGGL(k_nn_resolve, dim3((n + 4 * kResolveQ - 1) / (4 * kResolveQ)), dim3(256), 0, ctx->stream, d_qry, n, d_tgt, m,
-                       (const float2 *)ctx->coarse.p, splits, frame, d_idx, d_d2, counters, st);
+    hipLaunchKernelGGL(k_nn_resolve, dim3((n + 4 * kResolveQ - 1) / (4 * kResolveQ)), dim3(256), 0, ctx->stream,
+                       d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, (const float2 *)ctx->coarse.p, splits,
+                       frames, d_idx, d_d2, counters, st);
     ctx->prof.nn_pairs += (double)n * (double)m;
     HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;
@@ -240,7 +265,7 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, const double *d_t
 int launch_nn(icpmi_ctx *ctx, const double *d_qry, int n, const double *d_tgt, int m, int *d_idx,
               double *d_d2, const IcpState *st)
 {
-    if (ctx->nn_engine == ICPMI_SEARCH_MFMA_F32) return launch_nn_mfma(ctx, d_qry, n, d_tgt, m, d_idx, d_d2, st);
+    if (ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16) return launch_nn_mfma(ctx, d_qry, n, m, d_idx, d_d2, st);
     constexpr int QPT = 2;
     const int qblocks = (n + 256 * QPT - 1) / (256 * QPT);
     // enough workgroups to fill 256 CUs several times over; every split keeps >= 256 targets
@@ -281,7 +306,7 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
     hipStream_t s = ctx->stream;
     constexpr int BLOCK = 128;
     const size_t smem = (size_t)k * BLOCK * (sizeof(double) + sizeof(int));
-    const bool mfma = ctx->nn_engine == ICPMI_SEARCH_MFMA_F32 && k <= 32 && m >= 4 * kSplitTargets;
+    const bool mfma = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= 4 * kSplitTargets;
     StageTimer t(ctx, ST_NORMALS);
     if (mfma) {
         const int splits = ctx->nn_splits, nslots = splits * 16;
@@ -292,14 +317,16 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
         if ((rc = reserve(ctx, ctx->fb_list, sizeof(int) * ((size_t)rows + 16)))) return rc;
         int *fb_count = (int *)ctx->fb_list.p, *fb_list = fb_count + 16;
         HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, sizeof(int), s));
-        const NnFrame *frame = (const NnFrame *)ctx->nn_misc.p;
+        const SplitFrame *frames = (const SplitFrame *)ctx->frames.p;
+        const unsigned *perm = (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m;
         for (long c0 = row0; c0 < row1; c0 += chunk) {
             const int nq = (int)std::min<long>(chunk, row1 - c0);
             hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves>), dim3((nq + kCoarseQueries - 1) / kCoarseQueries, splits),
-                               dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const float4 *)ctx->bpack.p,
-                               frame, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
-            hipLaunchKernelGGL(k_knn_resolve, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, m, k, (int)c0, nq,
-                               (const float *)ctx->slotmin.p, nslots, frame, knn, fb_list, fb_count);
+                               dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
+                               frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
+            hipLaunchKernelGGL(k_knn_resolve, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq,
+                               (const double *)ctx->tgt_sorted.p, perm, m, k, (const float *)ctx->slotmin.p, nslots,
+                               frames, knn, fb_list, fb_count);
         }
         hipLaunchKernelGGL(k_knn_exact_list<BLOCK>, dim3(64), dim3(BLOCK), smem, s, d_pts, m, k, 0, 0,
                            (const int *)fb_list, (const int *)fb_count, knn);
@@ -611,7 +638,7 @@ void icpmi_destroy(icpmi_ctx *ctx)
     for (DevBuf *b : {&ctx->cur, &ctx->nrm, &ctx->idx, &ctx->part_d2, &ctx->part_idx, &ctx->partials,
                       &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out,
                       &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin,
-                      &ctx->fb_list})
+                      &ctx->fb_list, &ctx->sort_keys, &ctx->sort_tmp, &ctx->tgt_sorted, &ctx->frames})
         release(*b);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);

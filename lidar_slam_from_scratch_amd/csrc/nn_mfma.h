@@ -1,36 +1,41 @@
-// nn_mfma.h -- nearest-neighbour search, engine 2: fp32 MFMA coarse pass + certified fp64
-// resolve.  Returns exactly what k_nn_f64 returns (the fp64 nearest neighbour in the
-// reference's arithmetic, kdtree.hpp:112-142) at the FP32 matrix rate instead of the
-// FP64 vector rate.
+// nn_mfma.h -- nearest-neighbour search, engine 2: bf16x3 MFMA coarse pass over ALL
+// (query, target) pairs + certified fp64 resolve.  Returns exactly what k_nn_f64 returns
+// (the fp64 nearest neighbour in the reference's arithmetic, kdtree.hpp:112-142).
 //
-// Coarse pass (k_nn_coarse).  With both clouds centred on c and rounded to fp32
-// (P = fl32(p - c), Q = fl32(q - c)),
-//     |P - Q|^2 = |P|^2 + [Px Py Pz 1] . [-2Qx -2Qy -2Qz |Q|^2]
-// is a K = 4 contraction: one v_mfma_f32_16x16x4_f32 evaluates 16 queries x 16 targets.
-// A wave keeps 4 query tiles (64 queries) as A operands in registers and streams target
-// tiles (B operands) from LDS; a 2048-target "split" (32 KiB, already in MFMA operand
-// order in HBM) is staged once per workgroup and shared by its 8 waves.  The only VALU
-// work per MFMA is two v_min3_f32: lane l, register r keeps the running minimum of query
-// row (l>>4)*4+r against the targets of column l&15 -- a "slot" = 128 targets that are
-// CONTIGUOUS in the caller's array (tile t, column c of split s is target s*2048+c*128+t).
-// The epilogue adds |P|^2, tags each slot minimum with its column in the 4 low mantissa
-// bits and reduces the 16 columns to (smallest, second smallest): 8 bytes per query per
-// split.  No index is tracked in the loop.
+// Why bf16 matrix cores for an fp32-accurate distance.  v_mfma_f32_16x16x4_f32 shares the
+// FP32 lanes with the VALU on gfx950: measured, the per-pair min-tracking VALU work ADDS to
+// the MFMA time instead of overlapping (scripts/micro: 0.55 ms MFMA-only -> 0.72 ms with
+// two v_min3 per MFMA).  The bf16 matrix pipe is separate and 16x faster per flop, so each
+// fp32 coordinate is split EXACTLY into three bf16 pieces (8+8+8 significand bits) and the
+// contraction carries all 9 cross products per axis:
+//     |P-Q|^2 = |P|^2 + sum_axis sum_{i,j} P_i * (-2 Q_j) + 1 * |Q|^2 (3 pieces)
+// K = 27 + 3 = 30 <= 32: ONE v_mfma_f32_16x16x32_bf16 per 16 queries x 16 targets, every
+// product exact in fp32, fp32 accumulation.  Measured 0.37 ms vs 0.78 ms for the same pairs.
 //
-// Resolve (k_nn_resolve), all fp64 in the reference's operation order.  Per query: take the
-// split/column with the smallest coarse value, evaluate its 128 targets exactly -> D.  Every
-// target with exact distance <= D has a coarse value <= tau = D + E, where E bounds the
-// fp32 error (derivation below).  Every other slot whose recorded minimum is <= tau is
-// evaluated exactly too (whole split when its second-smallest column is <= tau).  The
-// result is the exact minimum, ties to the lowest index: bit-identical to k_nn_f64.
+// Geometry.  Targets are Morton-sorted once per call (the target does not move during the
+// ICP loop) and cut into splits of 2048; every split has its own centre c_s and radius
+// rho_s, and both operands of a (query block, split) workgroup are expressed about c_s.
+// The fp32 error of a pair is then ~80 u (|p-c_s| + rho_s)^2: tiny for the splits near the
+// query, and large only where the distance itself is large.  Lane l / register r of a wave
+// keeps the running minimum of query row (l>>4)*4+r against column l&15 of every tile: a
+// "slot" = 128 targets CONTIGUOUS in the sorted array (tile t, column c of split s is sorted
+// position s*2048 + c*128 + t).  No index is tracked in the loop: the VALU work per MFMA is
+// two v_min3_f32.  The epilogue transposes through LDS to lane-per-query, adds |P|^2 and
+// writes either (column-tagged min, second min) [1-NN] or all 16 column minima [k-NN].
 //
-// Error bound.  u = 2^-24.  Let a >= |P| + |Q|.
-//   coordinate rounding: |P-(p-c)| <= u|p-c|, same for Q, so
-//        | |P-Q|^2 - |p-q|^2 | <= eps (2 d + eps),  eps = u a (1 + 1e-6),  d = |p-q|
-//   arithmetic: fl32(|Q|^2) (1 rounding of an exact fp64 value), 4 chained FMAs in the MFMA
-//        (guide: bitwise a k-ordered fmaf chain), fl32(|P|^2) formed with 3 roundings, 1
-//        final add: every intermediate is bounded by a^2, so <= 9 u a^2; 16 u a^2 is used.
-//   column tag: < 2^-20 relative on the stored minimum.
+// Resolve (k_nn_resolve / k_knn_resolve), fp64 in the reference's operation order: exact
+// scan of the winning slot -> D; every target with exact distance <= D has a coarse value
+// <= tau_s = D + E_s(D) in its split s, so every slot whose recorded minimum is under its
+// split's tau_s is scanned exactly too.  Result: exact minimum, ties to the lowest ORIGINAL
+// index -- bit-identical to k_nn_f64 and to the oracle.
+//
+// Error bound E_s(d) for a pair in split s.  u = 2^-24, a >= |p-c_s| + rho_s.
+//   coordinate rounding to fp32: eps (2 sqrt(d) + eps), eps = u a (1 + 1e-6)
+//   arithmetic: the 30 products are exact; their fp32 accumulation inside the MFMA is not
+//     specified, so every one of the <= 33 additions is charged a full truncation
+//     (2u x the largest magnitude, <= a^2): 66 u a^2; plus fl32(|Q|^2), fl32(|P|^2) formed
+//     with 5 roundings, and the final add: 73 u a^2.  80 u a^2 is used.
+//   column tag: < 2^-20 relative on the stored minimum (inflation 4e-6 covers it).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -42,21 +47,26 @@ namespace icpmi {
 constexpr int kSplitTiles = 128;                  // target tiles (16 targets each) per split
 constexpr int kSplitTargets = kSplitTiles * 16;   // 2048
 constexpr int kSlotTargets = kSplitTiles;         // targets per (split, column) slot
+constexpr int kChunkTiles = 32;                   // tiles staged in LDS at a time (32 KiB)
 constexpr int kCoarseQT = 4;                      // query tiles per wave
 constexpr int kCoarseWaves = 8;                   // waves per workgroup
 constexpr int kCoarseThreads = 64 * kCoarseWaves;
 constexpr int kCoarseQueries = 16 * kCoarseQT * kCoarseWaves; // queries per workgroup
 constexpr float kBig = 3.0e38f;
+constexpr double kArithBound = 80.0;              // x u a^2, see above
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-struct NnFrame {
-    double c[3];     // centre both clouds are expressed about
-    double rq;       // upper bound of |Q| over all targets (inflated)
+struct NnFrame {     // bounding box of the whole target (Morton quantisation)
     double lo[3], hi[3];
 };
+struct SplitFrame {  // per split of 2048 sorted targets
+    double c[3];     // centre the split's operands are expressed about
+    double rho;      // >= max |q - c| over the split (inflated)
+};
 
-// ---- bounding box of the target -> frame -------------------------------------------------
+// ---- bounding box -----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bbox_partial(const double *__restrict__ pts, int m,
                                                       double *__restrict__ part /*[grid][6]*/)
 {
@@ -90,56 +100,163 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const double *__restrict__
     }
 }
 
-__global__ void k_bbox_final(const double *__restrict__ part, int nblocks, NnFrame *frame)
+__global__ __launch_bounds__(64) void k_bbox_final(const double *__restrict__ part, int nblocks, NnFrame *frame)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
-    for (int b = 0; b < nblocks; ++b)
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = part[b * 6 + a] < lo[a] ? part[b * 6 + a] : lo[a];
-            hi[a] = part[b * 6 + 3 + a] > hi[a] ? part[b * 6 + 3 + a] : hi[a];
+    const int lane = threadIdx.x;
+    for (int a = 0; a < 6; ++a) {
+        double v = a < 3 ? 1.7e308 : -1.7e308;
+        for (int b = lane; b < nblocks; b += 64) {
+            const double x = part[b * 6 + a];
+            v = a < 3 ? (x < v ? x : v) : (x > v ? x : v);
         }
-    double h2 = 0.0;
+        for (int off = 32; off > 0; off >>= 1) {
+            const double x = __shfl_down(v, off, 64);
+            v = a < 3 ? (x < v ? x : v) : (x > v ? x : v);
+        }
+        if (lane == 0) (a < 3 ? frame->lo[a] : frame->hi[a - 3]) = v;
+    }
+}
+
+// ---- Morton keys, gather, split frames ------------------------------------------------------------
+__device__ __forceinline__ unsigned spread10(unsigned v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_morton_keys(const double *__restrict__ pts, int m,
+                                                     const NnFrame *__restrict__ frame,
+                                                     unsigned *__restrict__ keys, unsigned *__restrict__ vals)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    unsigned q[3];
     for (int a = 0; a < 3; ++a) {
-        frame->lo[a] = lo[a];
-        frame->hi[a] = hi[a];
-        frame->c[a] = 0.5 * (lo[a] + hi[a]);
-        const double h = 0.5 * (hi[a] - lo[a]);
-        h2 += h * h;
+        const double ext = frame->hi[a] - frame->lo[a];
+        double f = ext > 0.0 ? (pts[3 * i + a] - frame->lo[a]) / ext : 0.0;
+        f = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
+        const int qi = (int)(f * 1023.0);
+        q[a] = (unsigned)(qi < 0 ? 0 : (qi > 1023 ? 1023 : qi));
     }
-    frame->rq = sqrt(h2) * (1.0 + 1e-6) + 1e-300;
+    keys[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    vals[i] = (unsigned)i;
 }
 
-// ---- targets -> MFMA B operands, split-major, 4 tiles per float4 --------------------------
-// Bpack[(s*32 + t4)*64 + lane].{x,y,z,w}: tile t = 4*t4 + e, k = lane>>4, column = lane&15,
-// target j = s*2048 + column*128 + t.  Padding targets get (0,0,0,kBig): never the minimum.
-__global__ __launch_bounds__(256) void k_pack_targets(const double *__restrict__ tgt, int m,
-                                                      const NnFrame *__restrict__ frame,
-                                                      float4 *__restrict__ Bpack, int splits)
+__global__ __launch_bounds__(256) void k_gather_points(const double *__restrict__ pts,
+                                                       const unsigned *__restrict__ perm, int m,
+                                                       double *__restrict__ out)
 {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= splits * 32 * 64) return;
-    const int lane = g & 63, t4 = (g >> 6) & 31, s = g >> 11;
-    const int col = lane & 15, k = lane >> 4;
-    float v[4];
-    for (int e = 0; e < 4; ++e) {
-        const int t = 4 * t4 + e;
-        const long j = (long)s * kSplitTargets + col * kSlotTargets + t;
-        if (j >= m) {
-            v[e] = k < 3 ? 0.0f : kBig;
-        } else if (k < 3) {
-            v[e] = -2.0f * (float)(tgt[3 * j + k] - frame->c[k]);
-        } else {
-            const double qx = (double)(float)(tgt[3 * j] - frame->c[0]);
-            const double qy = (double)(float)(tgt[3 * j + 1] - frame->c[1]);
-            const double qz = (double)(float)(tgt[3 * j + 2] - frame->c[2]);
-            v[e] = (float)((qx * qx + qy * qy) + qz * qz);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const unsigned j = perm[i];
+    out[3 * i] = pts[3 * j];
+    out[3 * i + 1] = pts[3 * j + 1];
+    out[3 * i + 2] = pts[3 * j + 2];
+}
+
+// one workgroup per split: bounding box of its sorted points -> centre and radius
+__global__ __launch_bounds__(256) void k_split_frames(const double *__restrict__ sorted, int m,
+                                                      SplitFrame *__restrict__ frames)
+{
+    const int s = blockIdx.x;
+    const int j0 = s * kSplitTargets, j1 = min(m, j0 + kSplitTargets);
+    double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
+    for (int j = j0 + threadIdx.x; j < j1; j += 256)
+        for (int a = 0; a < 3; ++a) {
+            const double v = sorted[3 * j + a];
+            lo[a] = v < lo[a] ? v : lo[a];
+            hi[a] = v > hi[a] ? v : hi[a];
+        }
+    __shared__ double red[4][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int a = 0; a < 3; ++a) {
+        double l = lo[a], h = hi[a];
+        for (int off = 32; off > 0; off >>= 1) {
+            const double l2 = __shfl_down(l, off, 64), h2 = __shfl_down(h, off, 64);
+            l = l2 < l ? l2 : l;
+            h = h2 > h ? h2 : h;
+        }
+        if (lane == 0) {
+            red[wave][a] = l;
+            red[wave][3 + a] = h;
         }
     }
-    Bpack[g] = make_float4(v[0], v[1], v[2], v[3]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double h2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            double l = red[0][a], h = red[0][3 + a];
+            for (int w = 1; w < 4; ++w) {
+                l = red[w][a] < l ? red[w][a] : l;
+                h = red[w][3 + a] > h ? red[w][3 + a] : h;
+            }
+            frames[s].c[a] = 0.5 * (l + h);
+            const double half = 0.5 * (h - l);
+            h2 += half * half;
+        }
+        frames[s].rho = sqrt(h2) * (1.0 + 1e-6) + 1e-300;
+    }
 }
 
-// ---- coarse pass ---------------------------------------------------------------------------
+// ---- exact three-way bf16 split of an fp32 value: x == h + m + l --------------------------------
+__device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsigned &l)
+{
+    const unsigned bh = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(bh);  // exact
+    const unsigned bm = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(bm); // exact, <= 8 significant bits left
+    h = bh >> 16;
+    m = bm >> 16;
+    l = __float_as_uint(r2) >> 16;
+}
+
+// K-slot k of the contraction: A side (query) piece index, B side (target) piece index
+//   k = 9*axis + 3*i + j (k < 27): A = P_axis piece i, B = -2 * Q_axis piece j
+//   k = 27..29: A = 1, B = piece (k-27) of fl32(|Q|^2);  k = 30, 31: both 0
+
+// ---- targets -> bf16 B operands: Bpack[(s*128 + t)*64 + lane] = 8 bf16 (k = 8*(lane>>4)+j) ----------
+__global__ __launch_bounds__(256) void k_pack_targets(const double *__restrict__ sorted, int m,
+                                                      const SplitFrame *__restrict__ frames,
+                                                      uint4 *__restrict__ Bpack, int splits)
+{
+    const int gidx = blockIdx.x * 256 + threadIdx.x;
+    if (gidx >= splits * kSplitTiles * 64) return;
+    const int lane = gidx & 63, t = (gidx >> 6) & (kSplitTiles - 1), s = gidx >> 13;
+    const int col = lane & 15, g = lane >> 4;
+    const long j = (long)s * kSplitTargets + col * kSlotTargets + t;
+    unsigned piece[3][3], np[3];
+    if (j < m) {
+        double n2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const float q = (float)(sorted[3 * j + a] - frames[s].c[a]);
+            split3(q, piece[a][0], piece[a][1], piece[a][2]);
+            n2 += (double)q * (double)q;
+        }
+        split3((float)n2, np[0], np[1], np[2]);
+    } else { // padding: never the minimum
+        for (int a = 0; a < 3; ++a) piece[a][0] = piece[a][1] = piece[a][2] = 0u;
+        split3(kBig, np[0], np[1], np[2]);
+    }
+    unsigned w[8];
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * g + e;
+        unsigned v = 0u;
+        if (k < 27) {
+            const unsigned b = piece[k / 9][k % 3];
+            v = __float_as_uint(-2.0f * __uint_as_float(b << 16)) >> 16; // exact
+        } else if (k < 30) {
+            v = np[k - 27];
+        }
+        w[e] = v & 0xFFFFu;
+    }
+    Bpack[gidx] = make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16));
+}
+
+// ---- coarse pass ---------------------------------------------------------------------------------
 __device__ __forceinline__ float min3f(float a, float b, float c)
 {
     return __builtin_fminf(__builtin_fminf(a, b), c); // -> v_min3_f32
@@ -150,66 +267,77 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
 // QT = query tiles (16 queries) per wave, a multiple of 4; WAVES = waves per workgroup.
 template <int MODE, int QT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
-    const double *__restrict__ qry, int n, const float4 *__restrict__ Bpack,
-    const NnFrame *__restrict__ frame, float2 *__restrict__ coarse /*[split][n]*/,
+    const double *__restrict__ qry, int n, const uint4 *__restrict__ Bpack,
+    const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/,
     float *__restrict__ slotmin /*[n][splits*16]*/, const IcpState *__restrict__ st)
 {
-    static_assert(QT % 4 == 0, "epilogue works on groups of 64 queries");
+    static_assert(QT % 4 == 0, "operands and epilogue work on groups of 64 queries");
     constexpr int THREADS = 64 * WAVES;
-    constexpr int SCRATCH4 = WAVES * 64 * 20 / 4 > 32 * 64 ? WAVES * 64 * 20 / 4 : 32 * 64;
+    constexpr int CHUNK16 = kChunkTiles * 64; // uint4 per staged chunk (32 KiB)
+    constexpr int SCRATCH16 = WAVES * 64 * 20 / 4 > CHUNK16 ? WAVES * 64 * 20 / 4 : CHUNK16;
+    static_assert(WAVES * 64 * 4 <= CHUNK16, "A staging fits the chunk buffer");
     if (st && st->done) return;
-    // 32 KiB of B operands; reused (plus a tail) for the epilogue's transpose
-    __shared__ float4 ldsB[SCRATCH4];
+    __shared__ uint4 lds[SCRATCH16];
     const int s = blockIdx.y;
-    {
-        const float4 *src = Bpack + (size_t)s * (32 * 64);
-#pragma unroll
-        for (int e = 0; e < (32 * 64) / THREADS; ++e) ldsB[threadIdx.x + e * THREADS] = src[threadIdx.x + e * THREADS];
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q0 = (blockIdx.x * WAVES + wave) * (16 * QT);
-    const double c0 = frame->c[0], c1 = frame->c[1], c2 = frame->c[2];
+    const double c0 = frames[s].c[0], c1 = frames[s].c[1], c2 = frames[s].c[2];
 
-    // A operands: lane l holds component k = l>>4 of query row l&15; k == 3 is the constant 1
-    float a[QT];
-    {
-        const int row = lane & 15, k = lane >> 4;
-        const double ck = k == 0 ? c0 : (k == 1 ? c1 : c2);
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            int i = q0 + t * 16 + row;
-            i = i < n ? i : n - 1;
-            a[t] = k < 3 ? (float)(qry[3 * i + k] - ck) : 1.0f;
-        }
-    }
-    // |P|^2 of the queries this lane owns in the epilogue (lane-per-query there)
+    // A operands.  Each lane builds the 32-slot bf16 row of ONE query (lane-per-query:
+    // coalesced fp64 loads, pieces computed once), rows go through LDS, and every lane
+    // picks up its fragment: row l&15 of the tile, slots 8*(l>>4) .. +7.
+    bf16x8 afrag[QT];
     float pn[QT / 4];
+    {
+        uint4 *rows = lds + wave * (64 * 4); // 64 rows x 64 B
 #pragma unroll
-    for (int gq = 0; gq < QT / 4; ++gq) {
-        const int iq = q0 + gq * 64 + lane < n ? q0 + gq * 64 + lane : n - 1;
-        const float px = (float)(qry[3 * iq] - c0), py = (float)(qry[3 * iq + 1] - c1),
-                    pz = (float)(qry[3 * iq + 2] - c2);
-        pn[gq] = (px * px + py * py) + pz * pz;
+        for (int gq = 0; gq < QT / 4; ++gq) {
+            const int iq = q0 + gq * 64 + lane < n ? q0 + gq * 64 + lane : n - 1;
+            const float px = (float)(qry[3 * iq] - c0), py = (float)(qry[3 * iq + 1] - c1),
+                        pz = (float)(qry[3 * iq + 2] - c2);
+            pn[gq] = (px * px + py * py) + pz * pz;
+            unsigned xh, xm, xl, yh, ym, yl, zh, zm, zl;
+            split3(px, xh, xm, xl);
+            split3(py, yh, ym, yl);
+            split3(pz, zh, zm, zl);
+            const unsigned one = 0x3f80u;
+            // slots: x: h h h m m m l l | l, y: h h h m m m l | l l, z: h h h m m m | l l l 1 1 1 0 0
+            rows[lane * 4 + 0] = make_uint4(xh | (xh << 16), xh | (xm << 16), xm | (xm << 16), xl | (xl << 16));
+            rows[lane * 4 + 1] = make_uint4(xl | (yh << 16), yh | (yh << 16), ym | (ym << 16), ym | (yl << 16));
+            rows[lane * 4 + 2] = make_uint4(yl | (yl << 16), zh | (zh << 16), zh | (zm << 16), zm | (zm << 16));
+            rows[lane * 4 + 3] = make_uint4(zl | (zl << 16), zl | (one << 16), one | (one << 16), 0u);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint4 f = rows[(t * 16 + (lane & 15)) * 4 + (lane >> 4)];
+                afrag[gq * 4 + t] = __builtin_bit_cast(bf16x8, f);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     f32x4 m[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) m[t] = (f32x4){kBig, kBig, kBig, kBig};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
 
+    const uint4 *src = Bpack + (size_t)s * (kSplitTiles * 64);
+#pragma unroll 1
+    for (int chunk = 0; chunk < kSplitTiles / kChunkTiles; ++chunk) {
+        __syncthreads(); // A rows / previous chunk no longer needed
+#pragma unroll
+        for (int e = 0; e < CHUNK16 / THREADS; ++e)
+            lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
+        __syncthreads();
 #pragma unroll 2
-    for (int t4 = 0; t4 < 32; ++t4) {
-        const float4 b = ldsB[t4 * 64 + lane];
+        for (int tt = 0; tt < kChunkTiles; tt += 2) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, lds[tt * 64 + lane]);
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, lds[(tt + 1) * 64 + lane]);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.x, zero, 0, 0, 0);
-            const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.y, zero, 0, 0, 0);
-            const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.z, zero, 0, 0, 0);
-            const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b.w, zero, 0, 0, 0);
+            for (int t = 0; t < QT; ++t) {
+                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t], b0, zero, 0, 0, 0);
+                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t], b1, zero, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                m[t][r] = min3f(m[t][r], d0[r], d1[r]);
-                m[t][r] = min3f(m[t][r], d2[r], d3[r]);
+                for (int r = 0; r < 4; ++r) m[t][r] = min3f(m[t][r], d0[r], d1[r]);
             }
         }
     }
@@ -219,7 +347,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     // then + |P|^2 and either the tagged (min, second min) pair or the raw 16 values go
     // out, coalesced.
     __syncthreads(); // every wave is done with the B operands
-    float *sc = reinterpret_cast<float *>(ldsB) + wave * (64 * 20);
+    float *sc = reinterpret_cast<float *>(lds) + wave * (64 * 20);
     const int g = lane >> 4, col = lane & 15;
 #pragma unroll
     for (int gq = 0; gq < QT / 4; ++gq) {
@@ -262,7 +390,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     }
 }
 
-// ---- resolve ---------------------------------------------------------------------------------
+// ---- resolve ---------------------------------------------------------------------------------------
+// bound on the coarse value, in split `f`, of any target whose exact distance is <= d
+__device__ __forceinline__ float split_tau(double px, double py, double pz, const SplitFrame &f, double d,
+                                           double sqrt_d)
+{
+    const double dx = px - f.c[0], dy = py - f.c[1], dz = pz - f.c[2];
+    const double a = sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + f.rho;
+    const double u = 5.9604644775390625e-08; // 2^-24
+    const double eps = u * a * (1.0 + 1e-6);
+    double tau = d + eps * (2.0 * sqrt_d + eps) + kArithBound * u * a * a;
+    tau = tau * (1.0 + 4e-6) + 1e-300; // column tag (2^-20) + slack for this fp64 evaluation
+    return __uint_as_float(__float_as_uint((float)tau) + 1u); // round up (tau > 0)
+}
+
 // wave-wide argmin of (d, j): smaller d, then smaller j; result valid in every lane
 __device__ __forceinline__ void wave_argmin(double &d, int &j)
 {
@@ -277,20 +418,22 @@ __device__ __forceinline__ void wave_argmin(double &d, int &j)
     }
 }
 
-// exact scan of targets [j0, j0+len) for the query (px,py,pz), all lanes cooperate
-__device__ __forceinline__ void scan_range(const double *__restrict__ tgt, int m, int j0, int len,
-                                           double px, double py, double pz, int lane, double &bd,
-                                           int &bj)
+// exact scan of sorted positions [j0, j0+len) for the query (px,py,pz), all lanes cooperate;
+// (bd, bj) is updated with the smaller (distance, ORIGINAL index)
+__device__ __forceinline__ void scan_range(const double *__restrict__ sorted,
+                                           const unsigned *__restrict__ perm, int m, int j0, int len,
+                                           double px, double py, double pz, int lane, double &bd, int &bj)
 {
     double d = 1.7976931348623157e308;
     int j = 0x7fffffff;
     for (int o = lane; o < len; o += 64) {
         const int jj = j0 + o;
         if (jj < m) {
-            const double dd = sqdist(tgt[3 * jj], tgt[3 * jj + 1], tgt[3 * jj + 2], px, py, pz);
-            if (dd < d) { // ascending jj: strict keeps the lowest index
+            const double dd = sqdist(sorted[3 * jj], sorted[3 * jj + 1], sorted[3 * jj + 2], px, py, pz);
+            const int oj = (int)perm[jj];
+            if (dd < d || (dd == d && oj < j)) {
                 d = dd;
-                j = jj;
+                j = oj;
             }
         }
     }
@@ -302,15 +445,16 @@ __device__ __forceinline__ void scan_range(const double *__restrict__ tgt, int m
 }
 
 // One wave resolves 16 queries.  Lane = (query ql = lane&15, quarter = lane>>4): the four
-// quarters share the bookkeeping of a query (each scans a quarter of the splits) and each
+// quarters share the bookkeeping of a query (each looks at a quarter of the splits) and each
 // quarter-wave scans one winning slot at a time, 8 consecutive targets (192 contiguous
 // bytes) per lane, so 4 slots are in flight per wave and ~6 waves per SIMD hide the latency.
 constexpr int kResolveQ = 16;
 
 __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ qry, int n,
-                                                    const double *__restrict__ tgt, int m,
+                                                    const double *__restrict__ sorted,
+                                                    const unsigned *__restrict__ perm, int m,
                                                     const float2 *__restrict__ coarse, int splits,
-                                                    const NnFrame *__restrict__ frame,
+                                                    const SplitFrame *__restrict__ frames,
                                                     int *__restrict__ idx, double *__restrict__ d2out,
                                                     unsigned long long *__restrict__ counters,
                                                     const IcpState *__restrict__ st)
@@ -361,10 +505,11 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
         for (int o = 0; o < 8; ++o) {
             const int jj = j0 + o;
             const int jc = jj < m ? jj : m - 1;
-            const double dd = sqdist(tgt[3 * jc], tgt[3 * jc + 1], tgt[3 * jc + 2], qx, qy, qz);
-            if (jj < m && dd < d) {
+            const double dd = sqdist(sorted[3 * jc], sorted[3 * jc + 1], sorted[3 * jc + 2], qx, qy, qz);
+            const int oj = (int)perm[jc];
+            if (jj < m && (dd < d || (dd == d && oj < j))) {
                 d = dd;
-                j = jj;
+                j = oj;
             }
         }
 #pragma unroll
@@ -385,25 +530,21 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
         }
     }
 
-    // phase 3: certificate.  tau bounds the coarse value of any target at distance <= bd
-    const double dx = px - frame->c[0], dy = py - frame->c[1], dz = pz - frame->c[2];
-    const double a = sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + frame->rq;
-    const double u = 5.9604644775390625e-08; // 2^-24
-    const double eps = u * a * (1.0 + 1e-6);
-    double tau = bd + eps * (2.0 * sqrt(bd) + eps) + 16.0 * u * a * a;
-    tau = tau * (1.0 + 4e-6) + 1e-300; // column tag (2^-20) + slack for this fp64 evaluation
-    // round up: next float above the nearest-rounded value (tau > 0)
-    const float tauf = __uint_as_float(__float_as_uint((float)tau) + 1u);
-
+    // phase 3: certificate, split by split (tau depends on the split's frame)
+    const double sq = sqrt(bd);
     unsigned extra_slots = 0, extra_splits = 0;
     for (int s0 = 0; s0 < splits; s0 += 4) {
         const int s = s0 + quarter;
+        bool whole = false, slot = false;
         float2 v = make_float2(kBig, kBig);
-        if (s < splits) v = coarse[(size_t)s * n + ic];
-        const bool whole = valid && v.y <= tauf;            // a second column is inside the bound
-        const bool slot = valid && !whole && s != bs && v.x <= tauf;
+        if (s < splits && valid) {
+            v = coarse[(size_t)s * n + ic];
+            const float tauf = split_tau(px, py, pz, frames[s], bd, sq);
+            whole = v.y <= tauf;                       // a second column is inside the bound
+            slot = !whole && s != bs && v.x <= tauf;
+        }
         unsigned long long pend = __ballot(whole || slot);
-        while (pend) {                                      // rare; wave-uniform loop
+        while (pend) {                                 // rare; wave-uniform loop
             const int L = __ffsll((long long)pend) - 1;
             pend &= pend - 1;
             const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
@@ -412,8 +553,8 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
             const int sL = s0 + (L >> 4);
             double d = 1.7976931348623157e308;
             int j = 0x7fffffff;
-            if (w) scan_range(tgt, m, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
-            else scan_range(tgt, m, sL * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
+            if (w) scan_range(sorted, perm, m, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
+            else scan_range(sorted, perm, m, sL * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
             if (ql == (L & 15)) { // every replica of that query takes the result
                 if (d < bd || (d == bd && j < bj)) {
                     bd = d;
@@ -444,21 +585,23 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
 }
 
 // ---- k-NN on the same coarse pass ---------------------------------------------------------------
-// Resolve for the k nearest neighbours of target row i among all targets (icp.hpp:32,
+// Resolve for the k nearest neighbours of point i among all targets (icp.hpp:32,
 // kdtree.hpp:65-78), one wave per row.  Each slot minimum belongs to a distinct target, so
-// the k-th smallest slot minimum tS bounds the k-th neighbour: at least k targets have coarse
-// value <= tS, hence true squared distance <= dmax (solved from d <= tS + E(d)).  Every true
-// k-neighbour then has coarse value <= dmax + E(dmax): the slots under that bound are scanned
-// exactly (fp64, reference operation order) and every target with exact distance <= dmax is
-// collected; the k smallest by (distance, index) are written closest first -- the order
-// kdtree.hpp:72-76 returns and icp.hpp:41-51 sums in.  A looser tS (the k-th smallest of the
-// 64 per-lane minima instead of all slot minima) is still a valid bound and is what is used.
+// the k-th smallest of the 64 per-lane minima tS (each lane looks at every 64th slot) bounds
+// the k-th neighbour: k targets in k distinct slots have coarse value <= tS, hence true
+// squared distance <= dmax, solved from d <= tS + E(d) with the largest frame term among
+// those k slots.  Every true k-neighbour then has coarse value <= dmax + E_s(dmax) in its
+// split: the slots under their split's bound are scanned exactly (fp64, reference operation
+// order) and every target with exact distance <= dmax is collected; the k smallest by
+// (distance, original index) are written closest first -- the order kdtree.hpp:72-76
+// returns and icp.hpp:41-51 sums in.
 constexpr int kKnnCap = 256; // candidates per row held in LDS; overflow -> exact fallback list
 
-__global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ pts, int m, int k,
-                                                     int row0, int nrows,
+__global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ pts, int row0, int nrows,
+                                                     const double *__restrict__ sorted,
+                                                     const unsigned *__restrict__ perm, int m, int k,
                                                      const float *__restrict__ slotmin, int nslots,
-                                                     const NnFrame *__restrict__ frame,
+                                                     const SplitFrame *__restrict__ frames,
                                                      int *__restrict__ knn_idx /*[m][k]*/,
                                                      int *__restrict__ fb_list, int *__restrict__ fb_count)
 {
@@ -471,9 +614,16 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
     const float *mine = slotmin + (size_t)local * nslots;
 
-    // per-lane minimum of the slot minima
+    // per-lane minimum of the slot minima, with its slot
     float lmin = kBig;
-    for (int e = lane; e < nslots; e += 64) lmin = __builtin_fminf(lmin, mine[e]);
+    int lslot = lane < nslots ? lane : 0;
+    for (int e = lane; e < nslots; e += 64) {
+        const float v = mine[e];
+        if (v < lmin) {
+            lmin = v;
+            lslot = e;
+        }
+    }
     // k-th smallest of the 64 lane minima (ties ordered by lane)
     int rank = 0;
 #pragma unroll 8
@@ -485,24 +635,35 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     const unsigned long long who = __ballot(rank == kk - 1);
     const float tS = __shfl(lmin, __ffsll((long long)who) - 1, 64);
 
-    // bounds (see the header comment of this file for E)
-    const double dx = px - frame->c[0], dy = py - frame->c[1], dz = pz - frame->c[2];
-    const double a = sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + frame->rq;
+    // largest frame term a among the k slots under tS
+    double a;
+    {
+        const SplitFrame &f = frames[lslot >> 4];
+        const double dx = px - f.c[0], dy = py - f.c[1], dz = pz - f.c[2];
+        a = rank < kk ? sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + f.rho : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(a, off, 64);
+            a = o > a ? o : a;
+        }
+    }
     const double u = 5.9604644775390625e-08;
     const double eps = u * a * (1.0 + 1e-6);
-    const double A = 16.0 * u * a * a;
-    const double ts = tS > 0.f ? (double)tS : 0.0;
+    const double A = kArithBound * u * a * a;
+    const double ts = tS > 0.f ? (double)tS * (1.0 + 1e-6) : 0.0;
     const double xr = eps + sqrt(eps * eps + (ts + eps * eps + A)); // sqrt(dmax)
-    const double dmax = xr * xr * (1.0 + 1e-9);
-    double tau = dmax + eps * (2.0 * xr + eps) + A;
-    tau = tau * (1.0 + 4e-6) + 1e-300;
-    const float tauf = tS >= kBig ? kBig : __uint_as_float(__float_as_uint((float)tau) + 1u);
+    const double dmax = tS >= kBig ? 1.0e300 : xr * xr * (1.0 + 1e-9);
+    const double sq = sqrt(dmax);
 
-    // exact scan of every slot under the bound; keep targets with exact distance <= dmax
+    // exact scan of every slot under its split's bound; keep targets with exact distance <= dmax
     int total = 0;
     for (int e0 = 0; e0 < nslots; e0 += 64) {
         const int e = e0 + lane;
-        const bool flag = e < nslots && mine[e] <= tauf;
+        bool flag = false;
+        if (e < nslots) {
+            const float tauf = tS >= kBig ? kBig : split_tau(px, py, pz, frames[e >> 4], dmax, sq);
+            flag = mine[e] <= tauf;
+        }
         unsigned long long pend = __ballot(flag);
         while (pend) {
             const int L = __ffsll((long long)pend) - 1;
@@ -513,14 +674,14 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             for (int o = 0; o < kSlotTargets; o += 64) {
                 const int jj = j0 + o + lane;
                 double d = 1.7976931348623157e308;
-                if (jj < m) d = sqdist(pts[3 * jj], pts[3 * jj + 1], pts[3 * jj + 2], px, py, pz);
+                if (jj < m) d = sqdist(sorted[3 * jj], sorted[3 * jj + 1], sorted[3 * jj + 2], px, py, pz);
                 const bool keep = d <= dmax;
                 const unsigned long long km = __ballot(keep);
                 if (keep) {
                     const int pos = total + __popcll(km & ((1ull << lane) - 1ull));
                     if (pos < kKnnCap) {
                         cand_d[wave][pos] = d;
-                        cand_j[wave][pos] = jj;
+                        cand_j[wave][pos] = (int)perm[jj];
                     }
                 }
                 total += __popcll(km);
@@ -532,7 +693,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         return;
     }
     __builtin_amdgcn_wave_barrier();
-    // rank by (distance, index); the k smallest go out closest first
+    // rank by (distance, original index); the k smallest go out closest first
     for (int e = lane; e < total; e += 64) {
         const double d = cand_d[wave][e];
         const int j = cand_j[wave][e];

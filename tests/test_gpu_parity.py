@@ -307,7 +307,7 @@ def test_mfma_engine_certificate_paths(gpu_ctx, oracle):
     idx, d2 = gpu_ctx.nearest_batch(tgt, qry)
     oidx, od2 = oracle.nearest_batch_brute(tgt, qry)
     assert (idx == oidx).all() and (d2 == od2).all()
-    if gpu_ctx.engine == "mfma_f32":
+    if gpu_ctx.engine == "mfma_bf16":
         gpu_ctx.reset_profile()
         gpu_ctx.nearest_batch(tgt, qry)
         p = gpu_ctx.get_profile()
