@@ -586,16 +586,32 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
 
 // ---- k-NN on the same coarse pass ---------------------------------------------------------------
 // Resolve for the k nearest neighbours of point i among all targets (icp.hpp:32,
-// kdtree.hpp:65-78), one wave per row.  Each slot minimum belongs to a distinct target, so
-// the k-th smallest of the 64 per-lane minima tS (each lane looks at every 64th slot) bounds
-// the k-th neighbour: k targets in k distinct slots have coarse value <= tS, hence true
-// squared distance <= dmax, solved from d <= tS + E(d) with the largest frame term among
-// those k slots.  Every true k-neighbour then has coarse value <= dmax + E_s(dmax) in its
-// split: the slots under their split's bound are scanned exactly (fp64, reference operation
-// order) and every target with exact distance <= dmax is collected; the k smallest by
-// (distance, original index) are written closest first -- the order kdtree.hpp:72-76
-// returns and icp.hpp:41-51 sums in.
-constexpr int kKnnCap = 256; // candidates per row held in LDS; overflow -> exact fallback list
+// kdtree.hpp:65-78), one wave per row.  Two upper bounds T on the k-th neighbour's exact
+// squared distance are formed and the smaller one used:
+//   (a) each slot minimum belongs to a distinct target, so the k-th smallest of the 64
+//       per-lane minima tS (lane l looks at slots l, l+64, ...) gives k targets with coarse
+//       value <= tS, hence exact distance <= dmax, solved from d <= tS + E(d) with the
+//       largest frame term among those k slots;
+//   (b) the slot with the smallest minimum (the row's own neighbourhood: targets are Morton
+//       sorted) is scanned exactly and the k-th smallest of its per-lane minima taken.
+// Every true k-neighbour then has coarse value <= T + E_s(T) in its split: the slots under
+// their split's bound are scanned exactly (fp64, reference operation order) and every target
+// with exact distance <= T is collected; the k smallest by (distance, original index) are
+// written closest first -- the order kdtree.hpp:72-76 returns and icp.hpp:41-51 sums in.
+constexpr int kKnnCap = 512; // candidates per row held in LDS; overflow -> exact fallback list
+
+// k-th smallest (k = kk, 1-based) of one double per lane; DBL_MAX when fewer than kk are finite
+__device__ __forceinline__ double wave_kth_smallest(double v, int lane, int kk)
+{
+    int rank = 0;
+#pragma unroll 8
+    for (int L = 0; L < 64; ++L) {
+        const double o = __shfl(v, L, 64);
+        rank += (o < v || (o == v && L < lane)) ? 1 : 0;
+    }
+    const unsigned long long who = __ballot(rank == kk - 1);
+    return __shfl(v, __ffsll((long long)who) - 1, 64);
+}
 
 __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ pts, int row0, int nrows,
                                                      const double *__restrict__ sorted,
@@ -613,6 +629,8 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     const int i = row0 + local;
     const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
     const float *mine = slotmin + (size_t)local * nslots;
+    const int kk = k < 64 ? k : 64;
+    const double kInf = 1.7976931348623157e308;
 
     // per-lane minimum of the slot minima, with its slot
     float lmin = kBig;
@@ -624,18 +642,15 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             lslot = e;
         }
     }
-    // k-th smallest of the 64 lane minima (ties ordered by lane)
+    // bound (a): k-th smallest of the 64 lane minima (ties ordered by lane)
     int rank = 0;
 #pragma unroll 8
     for (int L = 0; L < 64; ++L) {
         const float v = __shfl(lmin, L, 64);
         rank += (v < lmin || (v == lmin && L < lane)) ? 1 : 0;
     }
-    const int kk = k < 64 ? k : 64;
-    const unsigned long long who = __ballot(rank == kk - 1);
-    const float tS = __shfl(lmin, __ffsll((long long)who) - 1, 64);
-
-    // largest frame term a among the k slots under tS
+    const float tS = __shfl(lmin, __ffsll((long long)__ballot(rank == kk - 1)) - 1, 64);
+    const int bslot = __shfl(lslot, __ffsll((long long)__ballot(rank == 0)) - 1, 64);
     double a;
     {
         const SplitFrame &f = frames[lslot >> 4];
@@ -653,15 +668,50 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     const double ts = tS > 0.f ? (double)tS * (1.0 + 1e-6) : 0.0;
     const double xr = eps + sqrt(eps * eps + (ts + eps * eps + A)); // sqrt(dmax)
     const double dmax = tS >= kBig ? 1.0e300 : xr * xr * (1.0 + 1e-9);
-    const double sq = sqrt(dmax);
 
-    // exact scan of every slot under its split's bound; keep targets with exact distance <= dmax
+    // bound (b): exact scan of the best slot (two targets per lane)
+    double d0 = kInf, d1 = kInf;
+    int o0 = 0, o1 = 0;
+    {
+        const int j0 = (bslot >> 4) * kSplitTargets + (bslot & 15) * kSlotTargets;
+        const int ja = j0 + lane, jb = j0 + 64 + lane;
+        if (ja < m) {
+            d0 = sqdist(sorted[3 * ja], sorted[3 * ja + 1], sorted[3 * ja + 2], px, py, pz);
+            o0 = (int)perm[ja];
+        }
+        if (jb < m) {
+            d1 = sqdist(sorted[3 * jb], sorted[3 * jb + 1], sorted[3 * jb + 2], px, py, pz);
+            o1 = (int)perm[jb];
+        }
+    }
+    const double t1 = wave_kth_smallest(d0 < d1 ? d0 : d1, lane, kk);
+    const double T = t1 < dmax ? t1 : dmax;
+    const double sq = sqrt(T);
+
+    // candidates: the best slot's targets under T, then every other slot under its split's bound
     int total = 0;
+    {
+        const bool k0 = d0 <= T, k1 = d1 <= T;
+        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (k0) {
+            const int pos = __popcll(m0 & below);
+            cand_d[wave][pos] = d0; // at most 128 <= kKnnCap
+            cand_j[wave][pos] = o0;
+        }
+        total = __popcll(m0);
+        if (k1) {
+            const int pos = total + __popcll(m1 & below);
+            cand_d[wave][pos] = d1;
+            cand_j[wave][pos] = o1;
+        }
+        total += __popcll(m1);
+    }
     for (int e0 = 0; e0 < nslots; e0 += 64) {
         const int e = e0 + lane;
         bool flag = false;
-        if (e < nslots) {
-            const float tauf = tS >= kBig ? kBig : split_tau(px, py, pz, frames[e >> 4], dmax, sq);
+        if (e < nslots && e != bslot) {
+            const float tauf = T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[e >> 4], T, sq);
             flag = mine[e] <= tauf;
         }
         unsigned long long pend = __ballot(flag);
@@ -673,9 +723,9 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
 #pragma unroll
             for (int o = 0; o < kSlotTargets; o += 64) {
                 const int jj = j0 + o + lane;
-                double d = 1.7976931348623157e308;
+                double d = kInf;
                 if (jj < m) d = sqdist(sorted[3 * jj], sorted[3 * jj + 1], sorted[3 * jj + 2], px, py, pz);
-                const bool keep = d <= dmax;
+                const bool keep = d <= T;
                 const unsigned long long km = __ballot(keep);
                 if (keep) {
                     const int pos = total + __popcll(km & ((1ull << lane) - 1ull));
@@ -688,7 +738,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             }
         }
     }
-    if (total > kKnnCap) { // too many near-equidistant targets: hand the row to the exact kernel
+    if (total > kKnnCap) { // too many targets under the bound: hand the row to the exact kernel
         if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = i;
         return;
     }
