@@ -145,7 +145,8 @@ def main():
             "steady_state_it_per_s": args.steps / (prof["loop_ms"] * 1e-3) * (args.steps + 1) / args.steps
             if prof["loop_ms"] > 0 else None,
             "stage_ms": {k: prof[k] for k in ("nn_ms", "reduce_ms", "transform_ms", "normals_ms",
-                                              "loop_ms", "total_ms")},
+                                              "setup_ms", "loop_ms", "total_ms")},
+            "resolve_counters": {k: prof[k] for k in ("nn_recheck_queries", "nn_fallback_queries", "knn_fallback_rows")},
             "final_error": res.final_error,
             "roofline": {
                 "kernel": "correspondence search (nn pass)",

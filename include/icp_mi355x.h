@@ -83,8 +83,9 @@ typedef struct {
     double loop_ms;                                  /* iteration loop + post-loop pass only */
     double setup_ms;                                 /* Morton sort + operand packing of the target */
     double nn_pairs;                                 /* (source,target) pairs evaluated by nn passes */
-    int64_t nn_recheck_queries;                      /* queries re-resolved in fp64 (MFMA engine) */
-    int64_t nn_fallback_queries;                     /* queries sent to the fp64 exhaustive fallback */
+    int64_t nn_recheck_queries;                      /* extra 128-target slots scanned in fp64 (MFMA engine) */
+    int64_t nn_fallback_queries;                     /* whole 2048-target splits re-scanned in fp64 */
+    int64_t knn_fallback_rows;                       /* normal-estimation rows resolved by the exact k-NN kernel */
 } icpmi_profile;
 
 void icpmi_options_default(icpmi_options *opt);

@@ -51,7 +51,7 @@ class Profile(C.Structure):
                 ("total_ms", C.c_double), ("calls", C.c_int64), ("loop_ms", C.c_double),
                 ("setup_ms", C.c_double),
                 ("nn_pairs", C.c_double), ("nn_recheck_queries", C.c_int64),
-                ("nn_fallback_queries", C.c_int64)]
+                ("nn_fallback_queries", C.c_int64), ("knn_fallback_rows", C.c_int64)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)

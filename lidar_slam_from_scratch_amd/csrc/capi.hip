@@ -328,8 +328,14 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
                                (const double *)ctx->tgt_sorted.p, perm, m, k, (const float *)ctx->slotmin.p, nslots,
                                frames, knn, fb_list, fb_count);
         }
-        hipLaunchKernelGGL(k_knn_exact_list<BLOCK>, dim3(64), dim3(BLOCK), smem, s, d_pts, m, k, 0, 0,
-                           (const int *)fb_list, (const int *)fb_count, knn);
+        hipLaunchKernelGGL(k_knn_exact_rows, dim3(1024), dim3(256), (size_t)k * 256 * (sizeof(double) + sizeof(int)),
+                           s, d_pts, m, k, (const int *)fb_list, (const int *)fb_count, knn);
+        if (ctx->opt.profile) { // visibility only: how many rows took the exact path
+            int cnt = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&cnt, fb_count, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            ctx->prof.knn_fallback_rows += cnt;
+        }
     } else {
         hipLaunchKernelGGL(k_knn_exact_list<BLOCK>, dim3((rows + BLOCK - 1) / BLOCK), dim3(BLOCK), smem, s,
                            d_pts, m, k, row0, row1, (const int *)nullptr, (const int *)nullptr, knn);

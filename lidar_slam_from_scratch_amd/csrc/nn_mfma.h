@@ -134,9 +134,12 @@ __global__ __launch_bounds__(256) void k_morton_keys(const double *__restrict__ 
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
+    // one scale for all axes (the largest extent): Morton cells are cubes in space, so 128
+    // consecutive sorted points form a compact blob whatever the cloud's aspect ratio
+    double ext = 0.0;
+    for (int a = 0; a < 3; ++a) ext = frame->hi[a] - frame->lo[a] > ext ? frame->hi[a] - frame->lo[a] : ext;
     unsigned q[3];
     for (int a = 0; a < 3; ++a) {
-        const double ext = frame->hi[a] - frame->lo[a];
         double f = ext > 0.0 ? (pts[3 * i + a] - frame->lo[a]) / ext : 0.0;
         f = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
         const int qi = (int)(f * 1023.0);
@@ -754,6 +757,82 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             r += (df < d || (df == d && jf < j)) ? 1 : 0;
         }
         if (r < k) knn_idx[(size_t)i * k + r] = j;
+    }
+}
+
+// Exact fp64 k-NN list of ONE row per workgroup (rows the MFMA resolve hands back): every
+// thread keeps the k best of its strided share of the targets (sorted, in LDS), then the k
+// global best are popped by k rounds of a workgroup-wide argmin over the list heads.
+__global__ __launch_bounds__(256) void k_knn_exact_rows(const double *__restrict__ pts, int m, int k,
+                                                        const int *__restrict__ list,
+                                                        const int *__restrict__ list_count,
+                                                        int *__restrict__ knn_idx)
+{
+    extern __shared__ double knn_smem[];
+    constexpr int BLOCK = 256;
+    double *ld = knn_smem;
+    int *li = reinterpret_cast<int *>(knn_smem + (size_t)k * BLOCK);
+    __shared__ double red_d[4];
+    __shared__ int red_j[4], red_t[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrows = *list_count;
+    for (int lr = blockIdx.x; lr < nrows; lr += gridDim.x) { // block-uniform
+        const int i = list[lr];
+        const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+        int cnt = 0;
+        double thr = __builtin_inf();
+        for (int j = tid; j < m; j += BLOCK) {
+            const double d = sqdist(pts[3 * j], pts[3 * j + 1], pts[3 * j + 2], px, py, pz);
+            if (d < thr) {
+                int pos = cnt < k ? cnt : k - 1;
+                while (pos > 0) {
+                    const double prev = ld[(pos - 1) * BLOCK + tid];
+                    if (!(prev > d)) break;
+                    ld[pos * BLOCK + tid] = prev;
+                    li[pos * BLOCK + tid] = li[(pos - 1) * BLOCK + tid];
+                    --pos;
+                }
+                ld[pos * BLOCK + tid] = d;
+                li[pos * BLOCK + tid] = j;
+                if (cnt < k) ++cnt;
+                if (cnt == k) thr = ld[(k - 1) * BLOCK + tid];
+            }
+        }
+        int head = 0;
+        const int want = k < m ? k : m;
+        for (int out = 0; out < want; ++out) {
+            double d = head < cnt ? ld[head * BLOCK + tid] : 1.7976931348623157e308;
+            int j = head < cnt ? li[head * BLOCK + tid] : 0x7fffffff;
+            int t = tid;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double od = __shfl_xor(d, off, 64);
+                const int oj = __shfl_xor(j, off, 64), ot = __shfl_xor(t, off, 64);
+                if (od < d || (od == d && oj < j)) {
+                    d = od;
+                    j = oj;
+                    t = ot;
+                }
+            }
+            if (lane == 0) {
+                red_d[wave] = d;
+                red_j[wave] = j;
+                red_t[wave] = t;
+            }
+            __syncthreads();
+            d = red_d[0];
+            j = red_j[0];
+            t = red_t[0];
+            for (int w = 1; w < 4; ++w)
+                if (red_d[w] < d || (red_d[w] == d && red_j[w] < j)) {
+                    d = red_d[w];
+                    j = red_j[w];
+                    t = red_t[w];
+                }
+            if (tid == t) ++head;
+            if (tid == 0) knn_idx[(size_t)i * k + out] = j;
+            __syncthreads();
+        }
     }
 }
 
