@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -70,6 +71,8 @@ struct icpmi_ctx {
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
     int nn_splits = 0;
+    int coarse_qt = kCoarseQT;                // query tiles per wave of the coarse kernel (4 or 8)
+    int nn_ms = 0;                            // component stride of the SoA sorted target
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
     int32_t *h_flags = nullptr;    // pinned ring of done flags
@@ -216,7 +219,9 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     if ((rc = reserve(ctx, ctx->nn_misc, 256))) return rc;
     if ((rc = reserve(ctx, ctx->sort_keys, sizeof(unsigned) * 4 * (size_t)m))) return rc;
     if ((rc = reserve(ctx, ctx->sort_tmp, sort_bytes))) return rc;
-    if ((rc = reserve(ctx, ctx->tgt_sorted, sizeof(double) * 3 * (size_t)m))) return rc;
+    const int ms = (m + 63) / 64 * 64; // component stride of the SoA sorted copy
+    ctx->nn_ms = ms;
+    if ((rc = reserve(ctx, ctx->tgt_sorted, sizeof(double) * 3 * (size_t)ms))) return rc;
     if ((rc = reserve(ctx, ctx->frames, sizeof(SplitFrame) * (size_t)splits))) return rc;
     NnFrame *frame = (NnFrame *)ctx->nn_misc.p;
     unsigned *keys_in = (unsigned *)ctx->sort_keys.p, *keys_out = keys_in + m, *vals_in = keys_in + 2 * (size_t)m,
@@ -228,12 +233,12 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     hipLaunchKernelGGL(k_morton_keys, dim3((m + 255) / 256), dim3(256), 0, s, d_tgt, m, (const NnFrame *)frame,
                        keys_in, vals_in);
     HIP_TRY(ctx, sort_pairs_u32(ctx->sort_tmp.p, &sort_bytes, keys_in, keys_out, vals_in, perm, (unsigned)m, s));
-    hipLaunchKernelGGL(k_gather_points, dim3((m + 255) / 256), dim3(256), 0, s, d_tgt, (const unsigned *)perm, m,
+    hipLaunchKernelGGL(k_gather_points, dim3((m + 255) / 256), dim3(256), 0, s, d_tgt, (const unsigned *)perm, m, ms,
                        (double *)ctx->tgt_sorted.p);
-    hipLaunchKernelGGL(k_split_frames, dim3(splits), dim3(256), 0, s, (const double *)ctx->tgt_sorted.p, m,
+    hipLaunchKernelGGL(k_split_frames, dim3(splits), dim3(256), 0, s, (const double *)ctx->tgt_sorted.p, m, ms,
                        (SplitFrame *)ctx->frames.p);
     hipLaunchKernelGGL(k_pack_targets, dim3((splits * kSplitTiles * 64 + 255) / 256), dim3(256), 0, s,
-                       (const double *)ctx->tgt_sorted.p, m, (const SplitFrame *)ctx->frames.p,
+                       (const double *)ctx->tgt_sorted.p, m, ms, (const SplitFrame *)ctx->frames.p,
                        (uint4 *)ctx->bpack.p, splits);
     HIP_TRY(ctx, hipMemsetAsync((char *)ctx->nn_misc.p + 128, 0, 16, s));
     HIP_TRY(ctx, hipGetLastError());
@@ -250,11 +255,19 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     const unsigned *perm = (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m;
     unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);
     StageTimer t(ctx, ST_NN);
-    hipLaunchKernelGGL((k_nn_coarse<0, kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
-                       dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,
-                       (float2 *)ctx->coarse.p, (float *)nullptr, st);
+    if (ctx->coarse_qt == 8) {
+        constexpr int QPB = 16 * 8 * kCoarseWaves;
+        hipLaunchKernelGGL((k_nn_coarse<0, 8, kCoarseWaves>), dim3((n + QPB - 1) / QPB, splits), dim3(kCoarseThreads), 0,
+                           ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames, (float2 *)ctx->coarse.p,
+                           (float *)nullptr, st);
+    } else {
+        constexpr int QPB = 16 * 4 * kCoarseWaves;
+        hipLaunchKernelGGL((k_nn_coarse<0, 4, kCoarseWaves>), dim3((n + QPB - 1) / QPB, splits), dim3(kCoarseThreads), 0,
+                           ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames, (float2 *)ctx->coarse.p,
+                           (float *)nullptr, st);
+    }
     hipLaunchKernelGGL(k_nn_resolve, dim3((n + 4 * kResolveQ - 1) / (4 * kResolveQ)), dim3(256), 0, ctx->stream,
-                       d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, (const float2 *)ctx->coarse.p, splits,
+                       d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits,
                        frames, d_idx, d_d2, counters, st);
     ctx->prof.nn_pairs += (double)n * (double)m;
     HIP_TRY(ctx, hipGetLastError());
@@ -325,7 +338,7 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
                                dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
                                frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
             hipLaunchKernelGGL(k_knn_resolve, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq,
-                               (const double *)ctx->tgt_sorted.p, perm, m, k, (const float *)ctx->slotmin.p, nslots,
+                               (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots,
                                frames, knn, fb_list, fb_count);
         }
         hipLaunchKernelGGL(k_knn_exact_rows, dim3(1024), dim3(256), (size_t)k * 256 * (sizeof(double) + sizeof(int)),
@@ -614,6 +627,7 @@ int icpmi_create(const icpmi_options *opt, icpmi_ctx **out)
     icpmi_ctx *ctx = new icpmi_ctx();
     ctx->opt = o;
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = getenv("ICPMI_COARSE_QT")) ctx->coarse_qt = atoi(e) == 8 ? 8 : 4; // tuning knob
     memset(&ctx->prof, 0, sizeof(ctx->prof));
     auto bail = [&](const char *what) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(hipGetLastError());

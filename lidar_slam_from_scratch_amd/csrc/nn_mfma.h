@@ -61,6 +61,13 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 struct NnFrame {     // bounding box of the whole target (Morton quantisation)
     double lo[3], hi[3];
 };
+// The Morton-sorted copy of the target is stored SoA -- x[0..m), y[0..m), z[0..m) with the
+// component stride `ms` (m rounded up to 64) -- so that a run of consecutive sorted positions
+// is read as three fully coalesced streams.
+#define ICPMI_SX(sorted, ms, j) (sorted)[(j)]
+#define ICPMI_SY(sorted, ms, j) (sorted)[(size_t)(ms) + (j)]
+#define ICPMI_SZ(sorted, ms, j) (sorted)[2 * (size_t)(ms) + (j)]
+
 struct SplitFrame {  // per split of 2048 sorted targets
     double c[3];     // centre the split's operands are expressed about
     double rho;      // >= max |q - c| over the split (inflated)
@@ -150,19 +157,19 @@ __global__ __launch_bounds__(256) void k_morton_keys(const double *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_gather_points(const double *__restrict__ pts,
-                                                       const unsigned *__restrict__ perm, int m,
+                                                       const unsigned *__restrict__ perm, int m, int ms,
                                                        double *__restrict__ out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
     const unsigned j = perm[i];
-    out[3 * i] = pts[3 * j];
-    out[3 * i + 1] = pts[3 * j + 1];
-    out[3 * i + 2] = pts[3 * j + 2];
+    ICPMI_SX(out, ms, i) = pts[3 * j];
+    ICPMI_SY(out, ms, i) = pts[3 * j + 1];
+    ICPMI_SZ(out, ms, i) = pts[3 * j + 2];
 }
 
 // one workgroup per split: bounding box of its sorted points -> centre and radius
-__global__ __launch_bounds__(256) void k_split_frames(const double *__restrict__ sorted, int m,
+__global__ __launch_bounds__(256) void k_split_frames(const double *__restrict__ sorted, int m, int ms,
                                                       SplitFrame *__restrict__ frames)
 {
     const int s = blockIdx.x;
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void k_split_frames(const double *__restrict__
     double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
     for (int j = j0 + threadIdx.x; j < j1; j += 256)
         for (int a = 0; a < 3; ++a) {
-            const double v = sorted[3 * j + a];
+            const double v = sorted[(size_t)a * ms + j];
             lo[a] = v < lo[a] ? v : lo[a];
             hi[a] = v > hi[a] ? v : hi[a];
         }
@@ -222,7 +229,7 @@ __device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsign
 //   k = 27..29: A = 1, B = piece (k-27) of fl32(|Q|^2);  k = 30, 31: both 0
 
 // ---- targets -> bf16 B operands: Bpack[(s*128 + t)*64 + lane] = 8 bf16 (k = 8*(lane>>4)+j) ----------
-__global__ __launch_bounds__(256) void k_pack_targets(const double *__restrict__ sorted, int m,
+__global__ __launch_bounds__(256) void k_pack_targets(const double *__restrict__ sorted, int m, int ms,
                                                       const SplitFrame *__restrict__ frames,
                                                       uint4 *__restrict__ Bpack, int splits)
 {
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256) void k_pack_targets(const double *__restrict__
     if (j < m) {
         double n2 = 0.0;
         for (int a = 0; a < 3; ++a) {
-            const float q = (float)(sorted[3 * j + a] - frames[s].c[a]);
+            const float q = (float)(sorted[(size_t)a * ms + j] - frames[s].c[a]);
             split3(q, piece[a][0], piece[a][1], piece[a][2]);
             n2 += (double)q * (double)q;
         }
@@ -323,13 +330,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     for (int t = 0; t < QT; ++t) m[t] = (f32x4){kBig, kBig, kBig, kBig};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
+    // B operands: 4 chunks of 32 tiles through one 32 KiB LDS buffer; the next chunk is
+    // already in flight (global -> registers) while the current one is being consumed
     const uint4 *src = Bpack + (size_t)s * (kSplitTiles * 64);
+    uint4 pre[CHUNK16 / THREADS];
+#pragma unroll
+    for (int e = 0; e < CHUNK16 / THREADS; ++e) pre[e] = src[threadIdx.x + e * THREADS];
 #pragma unroll 1
     for (int chunk = 0; chunk < kSplitTiles / kChunkTiles; ++chunk) {
         __syncthreads(); // A rows / previous chunk no longer needed
 #pragma unroll
-        for (int e = 0; e < CHUNK16 / THREADS; ++e)
-            lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
+        for (int e = 0; e < CHUNK16 / THREADS; ++e) lds[threadIdx.x + e * THREADS] = pre[e];
+        if (chunk + 1 < kSplitTiles / kChunkTiles) {
+#pragma unroll
+            for (int e = 0; e < CHUNK16 / THREADS; ++e)
+                pre[e] = src[(size_t)(chunk + 1) * CHUNK16 + threadIdx.x + e * THREADS];
+        }
         __syncthreads();
 #pragma unroll 2
         for (int tt = 0; tt < kChunkTiles; tt += 2) {
@@ -424,7 +440,7 @@ __device__ __forceinline__ void wave_argmin(double &d, int &j)
 // exact scan of sorted positions [j0, j0+len) for the query (px,py,pz), all lanes cooperate;
 // (bd, bj) is updated with the smaller (distance, ORIGINAL index)
 __device__ __forceinline__ void scan_range(const double *__restrict__ sorted,
-                                           const unsigned *__restrict__ perm, int m, int j0, int len,
+                                           const unsigned *__restrict__ perm, int m, int ms, int j0, int len,
                                            double px, double py, double pz, int lane, double &bd, int &bj)
 {
     double d = 1.7976931348623157e308;
@@ -432,7 +448,7 @@ __device__ __forceinline__ void scan_range(const double *__restrict__ sorted,
     for (int o = lane; o < len; o += 64) {
         const int jj = j0 + o;
         if (jj < m) {
-            const double dd = sqdist(sorted[3 * jj], sorted[3 * jj + 1], sorted[3 * jj + 2], px, py, pz);
+            const double dd = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), px, py, pz);
             const int oj = (int)perm[jj];
             if (dd < d || (dd == d && oj < j)) {
                 d = dd;
@@ -449,13 +465,14 @@ __device__ __forceinline__ void scan_range(const double *__restrict__ sorted,
 
 // One wave resolves 16 queries.  Lane = (query ql = lane&15, quarter = lane>>4): the four
 // quarters share the bookkeeping of a query (each looks at a quarter of the splits) and each
-// quarter-wave scans one winning slot at a time, 8 consecutive targets (192 contiguous
-// bytes) per lane, so 4 slots are in flight per wave and ~6 waves per SIMD hide the latency.
+// quarter-wave scans one winning slot at a time (lane ql takes sorted positions ql, ql+16, ...
+// of the slot: three coalesced streams), so 4 slots are in flight per wave and ~6 waves per
+// SIMD hide the latency.
 constexpr int kResolveQ = 16;
 
 __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ qry, int n,
                                                     const double *__restrict__ sorted,
-                                                    const unsigned *__restrict__ perm, int m,
+                                                    const unsigned *__restrict__ perm, int m, int ms,
                                                     const float2 *__restrict__ coarse, int splits,
                                                     const SplitFrame *__restrict__ frames,
                                                     int *__restrict__ idx, double *__restrict__ d2out,
@@ -501,14 +518,14 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
         const int src = quarter * 4 + r; // the query this quarter scans now (a lane of quarter 0)
         const double qx = __shfl(px, src, 64), qy = __shfl(py, src, 64), qz = __shfl(pz, src, 64);
         const int s = __shfl(bs, src, 64), c = __shfl(bcol, src, 64);
-        const int j0 = s * kSplitTargets + c * kSlotTargets + ql * 8;
+        const int j0 = s * kSplitTargets + c * kSlotTargets + ql; // lane takes ql, ql+16, ...: coalesced
         double d = 1.7976931348623157e308;
         int j = 0x7fffffff;
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
-            const int jj = j0 + o;
+            const int jj = j0 + 16 * o;
             const int jc = jj < m ? jj : m - 1;
-            const double dd = sqdist(sorted[3 * jc], sorted[3 * jc + 1], sorted[3 * jc + 2], qx, qy, qz);
+            const double dd = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), qx, qy, qz);
             const int oj = (int)perm[jc];
             if (jj < m && (dd < d || (dd == d && oj < j))) {
                 d = dd;
@@ -556,8 +573,8 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
             const int sL = s0 + (L >> 4);
             double d = 1.7976931348623157e308;
             int j = 0x7fffffff;
-            if (w) scan_range(sorted, perm, m, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
-            else scan_range(sorted, perm, m, sL * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
+            if (w) scan_range(sorted, perm, m, ms, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
+            else scan_range(sorted, perm, m, ms, sL * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
             if (ql == (L & 15)) { // every replica of that query takes the result
                 if (d < bd || (d == bd && j < bj)) {
                     bd = d;
@@ -618,7 +635,7 @@ __device__ __forceinline__ double wave_kth_smallest(double v, int lane, int kk)
 
 __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ pts, int row0, int nrows,
                                                      const double *__restrict__ sorted,
-                                                     const unsigned *__restrict__ perm, int m, int k,
+                                                     const unsigned *__restrict__ perm, int m, int ms, int k,
                                                      const float *__restrict__ slotmin, int nslots,
                                                      const SplitFrame *__restrict__ frames,
                                                      int *__restrict__ knn_idx /*[m][k]*/,
@@ -679,11 +696,11 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         const int j0 = (bslot >> 4) * kSplitTargets + (bslot & 15) * kSlotTargets;
         const int ja = j0 + lane, jb = j0 + 64 + lane;
         if (ja < m) {
-            d0 = sqdist(sorted[3 * ja], sorted[3 * ja + 1], sorted[3 * ja + 2], px, py, pz);
+            d0 = sqdist(ICPMI_SX(sorted, ms, ja), ICPMI_SY(sorted, ms, ja), ICPMI_SZ(sorted, ms, ja), px, py, pz);
             o0 = (int)perm[ja];
         }
         if (jb < m) {
-            d1 = sqdist(sorted[3 * jb], sorted[3 * jb + 1], sorted[3 * jb + 2], px, py, pz);
+            d1 = sqdist(ICPMI_SX(sorted, ms, jb), ICPMI_SY(sorted, ms, jb), ICPMI_SZ(sorted, ms, jb), px, py, pz);
             o1 = (int)perm[jb];
         }
     }
@@ -727,7 +744,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             for (int o = 0; o < kSlotTargets; o += 64) {
                 const int jj = j0 + o + lane;
                 double d = kInf;
-                if (jj < m) d = sqdist(sorted[3 * jj], sorted[3 * jj + 1], sorted[3 * jj + 2], px, py, pz);
+                if (jj < m) d = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), px, py, pz);
                 const bool keep = d <= T;
                 const unsigned long long km = __ballot(keep);
                 if (keep) {
