@@ -72,6 +72,7 @@ struct icpmi_ctx {
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
     int nn_splits = 0;
     int coarse_qt = kCoarseQT;                // query tiles per wave of the coarse kernel (4 or 8)
+    int coarse_var = kCoarseVar;              // scheduling variant of the coarse kernel
     int nn_ms = 0;                            // component stride of the SoA sorted target
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
@@ -255,17 +256,21 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     const unsigned *perm = (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m;
     unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);
     StageTimer t(ctx, ST_NN);
-    if (ctx->coarse_qt == 8) {
-        constexpr int QPB = 16 * 8 * kCoarseWaves;
-        hipLaunchKernelGGL((k_nn_coarse<0, 8, kCoarseWaves>), dim3((n + QPB - 1) / QPB, splits), dim3(kCoarseThreads), 0,
-                           ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames, (float2 *)ctx->coarse.p,
-                           (float *)nullptr, st);
-    } else {
-        constexpr int QPB = 16 * 4 * kCoarseWaves;
-        hipLaunchKernelGGL((k_nn_coarse<0, 4, kCoarseWaves>), dim3((n + QPB - 1) / QPB, splits), dim3(kCoarseThreads), 0,
-                           ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames, (float2 *)ctx->coarse.p,
-                           (float *)nullptr, st);
+#define ICPMI_COARSE(QT, VAR)                                                                              \
+    hipLaunchKernelGGL((k_nn_coarse<0, QT, kCoarseWaves, VAR>), dim3((n + 16 * QT * kCoarseWaves - 1) / (16 * QT * kCoarseWaves), splits), \
+                       dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,      \
+                       (float2 *)ctx->coarse.p, (float *)nullptr, st)
+    switch (ctx->coarse_qt * 4 + ctx->coarse_var) {
+    case 8 * 4 + 0: ICPMI_COARSE(8, 0); break;
+    case 8 * 4 + 1: ICPMI_COARSE(8, 1); break;
+    case 8 * 4 + 2: ICPMI_COARSE(8, 2); break;
+    case 8 * 4 + 3: ICPMI_COARSE(8, 3); break;
+    case 4 * 4 + 1: ICPMI_COARSE(4, 1); break;
+    case 4 * 4 + 2: ICPMI_COARSE(4, 2); break;
+    case 4 * 4 + 3: ICPMI_COARSE(4, 3); break;
+    default: ICPMI_COARSE(4, 0); break;
     }
+#undef ICPMI_COARSE
     hipLaunchKernelGGL(k_nn_resolve, dim3((n + 4 * kResolveQ - 1) / (4 * kResolveQ)), dim3(256), 0, ctx->stream,
                        d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits,
                        frames, d_idx, d_d2, counters, st);
@@ -334,7 +339,7 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
         const unsigned *perm = (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m;
         for (long c0 = row0; c0 < row1; c0 += chunk) {
             const int nq = (int)std::min<long>(chunk, row1 - c0);
-            hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves>), dim3((nq + kCoarseQueries - 1) / kCoarseQueries, splits),
+            hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves, kCoarseVar>), dim3((nq + kCoarseQueries - 1) / kCoarseQueries, splits),
                                dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
                                frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
             hipLaunchKernelGGL(k_knn_resolve, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq,
@@ -627,7 +632,8 @@ int icpmi_create(const icpmi_options *opt, icpmi_ctx **out)
     icpmi_ctx *ctx = new icpmi_ctx();
     ctx->opt = o;
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *e = getenv("ICPMI_COARSE_QT")) ctx->coarse_qt = atoi(e) == 8 ? 8 : 4; // tuning knob
+    if (const char *e = getenv("ICPMI_COARSE_QT")) ctx->coarse_qt = atoi(e) == 8 ? 8 : 4; // tuning knobs
+    if (const char *e = getenv("ICPMI_COARSE_VAR")) ctx->coarse_var = atoi(e) & 3;
     memset(&ctx->prof, 0, sizeof(ctx->prof));
     auto bail = [&](const char *what) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(hipGetLastError());

@@ -50,6 +50,7 @@ constexpr int kSlotTargets = kSplitTiles;         // targets per (split, column)
 constexpr int kChunkTiles = 32;                   // tiles staged in LDS at a time (32 KiB)
 constexpr int kCoarseQT = 4;                      // query tiles per wave
 constexpr int kCoarseWaves = 8;                   // waves per workgroup
+constexpr int kCoarseVar = 0;                     // default scheduling variant (see k_nn_coarse)
 constexpr int kCoarseThreads = 64 * kCoarseWaves;
 constexpr int kCoarseQueries = 16 * kCoarseQT * kCoarseWaves; // queries per workgroup
 constexpr float kBig = 3.0e38f;
@@ -275,7 +276,9 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
 // MODE 0: 1-NN epilogue -> coarse[split][n] = (tagged min, second min over columns)
 // MODE 1: k-NN epilogue  -> slotmin[query][split*16 + column], every column minimum kept
 // QT = query tiles (16 queries) per wave, a multiple of 4; WAVES = waves per workgroup.
-template <int MODE, int QT, int WAVES>
+// VAR bit 0: software-pipeline the min3 one query tile behind its MFMAs; bit 1: keep the
+// next B chunk in flight in registers while the current one is consumed.
+template <int MODE, int QT, int WAVES, int VAR>
 __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     const double *__restrict__ qry, int n, const uint4 *__restrict__ Bpack,
     const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/,
@@ -330,21 +333,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     for (int t = 0; t < QT; ++t) m[t] = (f32x4){kBig, kBig, kBig, kBig};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
-    // B operands: 4 chunks of 32 tiles through one 32 KiB LDS buffer; the next chunk is
-    // already in flight (global -> registers) while the current one is being consumed
+    // B operands: 4 chunks of 32 tiles through one 32 KiB LDS buffer
+    constexpr bool PIPE = VAR & 1, PREFETCH = VAR & 2;
     const uint4 *src = Bpack + (size_t)s * (kSplitTiles * 64);
     uint4 pre[CHUNK16 / THREADS];
+    if (PREFETCH) {
 #pragma unroll
-    for (int e = 0; e < CHUNK16 / THREADS; ++e) pre[e] = src[threadIdx.x + e * THREADS];
+        for (int e = 0; e < CHUNK16 / THREADS; ++e) pre[e] = src[threadIdx.x + e * THREADS];
+    }
+    f32x4 p0 = {kBig, kBig, kBig, kBig}, p1 = p0; // PIPE: results whose min3 is still pending
 #pragma unroll 1
     for (int chunk = 0; chunk < kSplitTiles / kChunkTiles; ++chunk) {
         __syncthreads(); // A rows / previous chunk no longer needed
+        if (PREFETCH) {
 #pragma unroll
-        for (int e = 0; e < CHUNK16 / THREADS; ++e) lds[threadIdx.x + e * THREADS] = pre[e];
-        if (chunk + 1 < kSplitTiles / kChunkTiles) {
+            for (int e = 0; e < CHUNK16 / THREADS; ++e) lds[threadIdx.x + e * THREADS] = pre[e];
+            if (chunk + 1 < kSplitTiles / kChunkTiles) {
+#pragma unroll
+                for (int e = 0; e < CHUNK16 / THREADS; ++e)
+                    pre[e] = src[(size_t)(chunk + 1) * CHUNK16 + threadIdx.x + e * THREADS];
+            }
+        } else {
 #pragma unroll
             for (int e = 0; e < CHUNK16 / THREADS; ++e)
-                pre[e] = src[(size_t)(chunk + 1) * CHUNK16 + threadIdx.x + e * THREADS];
+                lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
         }
         __syncthreads();
 #pragma unroll 2
@@ -355,10 +367,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
             for (int t = 0; t < QT; ++t) {
                 const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t], b0, zero, 0, 0, 0);
                 const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t], b1, zero, 0, 0, 0);
+                if (PIPE) {
+                    // the two MFMAs above go out first; the VALU work is the PREVIOUS tile's,
+                    // whose results are already back (no wait states needed)
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int tp = (t + QT - 1) % QT;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) m[t][r] = min3f(m[t][r], d0[r], d1[r]);
+                    for (int r = 0; r < 4; ++r) m[tp][r] = min3f(m[tp][r], p0[r], p1[r]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    p0 = d0;
+                    p1 = d1;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m[t][r] = min3f(m[t][r], d0[r], d1[r]);
+                }
             }
         }
+    }
+    if (PIPE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[QT - 1][r] = min3f(m[QT - 1][r], p0[r], p1[r]);
     }
 
     // epilogue.  Transpose through LDS, 64 queries at a time, so that each lane owns ONE
