@@ -358,7 +358,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
             for (int e = 0; e < CHUNK16 / THREADS; ++e)
                 lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
         }
-        __syncthreads();
+        if (PREFETCH) {
+            // wait for the LDS stores only: __syncthreads() would also drain vmcnt and with
+            // it the prefetch that was just issued
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            __syncthreads();
+        }
 #pragma unroll 2
         for (int tt = 0; tt < kChunkTiles; tt += 2) {
             const bf16x8 b0 = __builtin_bit_cast(bf16x8, lds[tt * 64 + lane]);
