@@ -226,6 +226,42 @@ __global__ __launch_bounds__(64 * WAVES) void k_loop(const float4 *__restrict__ 
         }
         for (int t = 0; t < QT; ++t) for (int r = 0; r < 16; ++r) keep += mm[t][r];
     }
+    else if (VAR == 10 || VAR == 11) { // bf16 32x32x16, ONE MFMA (K = 16) per 32x32 tile (bf16x2 operands)
+        typedef short bf16x8 __attribute__((ext_vector_type(8)));
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        bf16x8 alo[QT];
+        for (int t = 0; t < QT; ++t) for (int e = 0; e < 8; ++e) alo[t][e] = (short)(0x3f80 + lane + t + e);
+        f32x16 mm[QT];
+        for (int t = 0; t < QT; ++t) for (int r = 0; r < 16; ++r) mm[t][r] = kBig;
+        f32x16 z16;
+        for (int r = 0; r < 16; ++r) z16[r] = 0.f;
+        const bf16x8 *ldsH = reinterpret_cast<const bf16x8 *>(ldsB);
+        f32x16 pa = z16, pb = z16;
+#pragma unroll 1
+        for (int tt = 0; tt < 64; tt += 2) { // 64 tiles of 32 targets = the same 2048 targets
+            const bf16x8 b0 = ldsH[(tt & 31) * 64 + lane], b1 = ldsH[((tt + 1) & 31) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const f32x16 da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], b0, z16, 0, 0, 0);
+                const f32x16 db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], b1, z16, 0, 0, 0);
+                if (VAR == 10) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mm[t][r] = min3f(mm[t][r], da[r], db[r]);
+                } else {
+                    const int tp = (t + QT - 1) % QT;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mm[tp][r] = min3f(mm[tp][r], pa[r], pb[r]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    pa = da;
+                    pb = db;
+                }
+            }
+        }
+        for (int t = 0; t < QT; ++t) for (int r = 0; r < 16; ++r) keep += mm[t][r];
+    }
     float acc = keep;
     for (int t = 0; t < QT; ++t) for (int r = 0; r < 4; ++r) acc += m[t][r];
     if (acc == (float)nevertrue) out[threadIdx.x] = acc;
@@ -258,6 +294,6 @@ int main()
     const double ideal_ms = (double)n * m / 256.0 * 32.0 / 1024.0 / 2.4e9 * 1e3;
 #define RUN(VAR, QT, W) { const int qpb = 16 * QT * W; float ms = timeit([&] { hipLaunchKernelGGL((k_loop<VAR, QT, W>), dim3((n + qpb - 1) / qpb, splits), dim3(64 * W), 0, 0, bp, out, -12345); }); printf("var %d QT=%d W=%d : %.3f ms  (%.1f%%)\n", VAR, QT, W, ms, 100 * ideal_ms / ms); }
 #define RUN32(VAR, QT, W) { const int qpb = 32 * QT * W; float ms = timeit([&] { hipLaunchKernelGGL((k_loop<VAR, QT, W>), dim3((n + qpb - 1) / qpb, splits), dim3(64 * W), 0, 0, bp, out, -12345); }); printf("var %d QT32=%d W=%d : %.3f ms  (%.1f%%)\n", VAR, QT, W, ms, 100 * ideal_ms / ms); }
-    RUN(6, 4, 8) RUN(6, 8, 8) RUN32(8, 2, 8) RUN32(9, 2, 8) RUN32(8, 4, 8) RUN32(9, 4, 8) RUN32(9, 2, 4) RUN32(9, 4, 4)
+    RUN(6, 4, 8) RUN(6, 8, 8) RUN32(10, 2, 8) RUN32(11, 2, 8) RUN32(10, 4, 8) RUN32(11, 4, 8) RUN32(10, 2, 4) RUN32(11, 2, 4) RUN32(10, 1, 8)
     return 0;
 }
