@@ -71,7 +71,7 @@ struct icpmi_ctx {
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
     int nn_splits = 0;
-    int coarse_qt = kCoarseQT;                // query tiles per wave of the coarse kernel (4 or 8)
+    int coarse_qt = kCoarseQT;                // 32-query tiles per wave of the coarse kernel (2 or 4)
     int coarse_var = kCoarseVar;              // scheduling variant of the coarse kernel
     int nn_ms = 0;                            // component stride of the SoA sorted target
     IcpState *d_state = nullptr;
@@ -257,18 +257,14 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);
     StageTimer t(ctx, ST_NN);
 #define ICPMI_COARSE(QT, VAR)                                                                              \
-    hipLaunchKernelGGL((k_nn_coarse<0, QT, kCoarseWaves, VAR>), dim3((n + 16 * QT * kCoarseWaves - 1) / (16 * QT * kCoarseWaves), splits), \
+    hipLaunchKernelGGL((k_nn_coarse<0, QT, kCoarseWaves, VAR>), dim3((n + kTile * QT * kCoarseWaves - 1) / (kTile * QT * kCoarseWaves), splits), \
                        dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,      \
                        (float2 *)ctx->coarse.p, (float *)nullptr, st)
-    switch (ctx->coarse_qt * 4 + ctx->coarse_var) {
-    case 8 * 4 + 0: ICPMI_COARSE(8, 0); break;
-    case 8 * 4 + 1: ICPMI_COARSE(8, 1); break;
-    case 8 * 4 + 2: ICPMI_COARSE(8, 2); break;
-    case 8 * 4 + 3: ICPMI_COARSE(8, 3); break;
-    case 4 * 4 + 1: ICPMI_COARSE(4, 1); break;
-    case 4 * 4 + 2: ICPMI_COARSE(4, 2); break;
-    case 4 * 4 + 3: ICPMI_COARSE(4, 3); break;
-    default: ICPMI_COARSE(4, 0); break;
+    switch (ctx->coarse_qt * 2 + (ctx->coarse_var & 1)) {
+    case 4 * 2 + 0: ICPMI_COARSE(4, 0); break;
+    case 4 * 2 + 1: ICPMI_COARSE(4, 1); break;
+    case 2 * 2 + 1: ICPMI_COARSE(2, 1); break;
+    default: ICPMI_COARSE(2, 0); break;
     }
 #undef ICPMI_COARSE
     hipLaunchKernelGGL(k_nn_resolve, dim3((n + 4 * kResolveQ - 1) / (4 * kResolveQ)), dim3(256), 0, ctx->stream,
@@ -327,7 +323,7 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
     const bool mfma = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= 4 * kSplitTargets;
     StageTimer t(ctx, ST_NORMALS);
     if (mfma) {
-        const int splits = ctx->nn_splits, nslots = splits * 16;
+        const int splits = ctx->nn_splits, nslots = splits * kCols;
         // bound the slot-minimum buffer (4 B x nslots per row) to ~1 GiB by chunking the rows
         long chunk = ((1l << 30) / ((long)nslots * 4)) / kCoarseQueries * kCoarseQueries;
         chunk = std::max<long>(kCoarseQueries, std::min<long>(chunk, ((long)rows + kCoarseQueries - 1) / kCoarseQueries * kCoarseQueries));
@@ -632,7 +628,7 @@ int icpmi_create(const icpmi_options *opt, icpmi_ctx **out)
     icpmi_ctx *ctx = new icpmi_ctx();
     ctx->opt = o;
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *e = getenv("ICPMI_COARSE_QT")) ctx->coarse_qt = atoi(e) == 8 ? 8 : 4; // tuning knobs
+    if (const char *e = getenv("ICPMI_COARSE_QT")) ctx->coarse_qt = atoi(e) == 4 ? 4 : 2; // tuning knobs
     if (const char *e = getenv("ICPMI_COARSE_VAR")) ctx->coarse_var = atoi(e) & 3;
     memset(&ctx->prof, 0, sizeof(ctx->prof));
     auto bail = [&](const char *what) {

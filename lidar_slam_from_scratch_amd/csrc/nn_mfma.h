@@ -1,27 +1,30 @@
-// nn_mfma.h -- nearest-neighbour search, engine 2: bf16x3 MFMA coarse pass over ALL
+// nn_mfma.h -- nearest-neighbour search, engine 2: bf16 MFMA coarse pass over ALL
 // (query, target) pairs + certified fp64 resolve.  Returns exactly what k_nn_f64 returns
 // (the fp64 nearest neighbour in the reference's arithmetic, kdtree.hpp:112-142).
 //
-// Why bf16 matrix cores for an fp32-accurate distance.  v_mfma_f32_16x16x4_f32 shares the
-// FP32 lanes with the VALU on gfx950: measured, the per-pair min-tracking VALU work ADDS to
-// the MFMA time instead of overlapping (scripts/micro: 0.55 ms MFMA-only -> 0.72 ms with
-// two v_min3 per MFMA).  The bf16 matrix pipe is separate and 16x faster per flop, so each
-// fp32 coordinate is split EXACTLY into three bf16 pieces (8+8+8 significand bits) and the
-// contraction carries all 9 cross products per axis:
-//     |P-Q|^2 = |P|^2 + sum_axis sum_{i,j} P_i * (-2 Q_j) + 1 * |Q|^2 (3 pieces)
-// K = 27 + 3 = 30 <= 32: ONE v_mfma_f32_16x16x32_bf16 per 16 queries x 16 targets, every
-// product exact in fp32, fp32 accumulation.  Measured 0.37 ms vs 0.78 ms for the same pairs.
+// Why bf16 matrix cores.  On gfx950 the per-pair min-tracking VALU work does not hide under
+// the MFMA: measured (scripts/micro), time ~ MFMA cycles + VALU cycles.  Ranking of the
+// candidates for 1e10 pairs, loop only:
+//     v_mfma_f32_16x16x4_f32   (fp32 operands, K = 4)            0.72-0.78 ms
+//     v_mfma_f32_16x16x32_bf16 (3 bf16 pieces per coordinate)    0.37-0.42 ms
+//     v_mfma_f32_32x32x16_bf16 (2 bf16 pieces per coordinate)    0.27-0.28 ms   <- used
+// Each centred fp32 coordinate is cut into two bf16 pieces (8 + 8 significand bits, the
+// second rounded to nearest: relative error <= 2^-16) and the contraction carries the 4
+// cross products per axis, plus |Q|^2 as three exact pieces against a constant 1:
+//     |P-Q|^2 ~ |P|^2 + sum_axis sum_{i,j<2} P_i * (-2 Q_j) + 1 * |Q|^2
+// K = 12 + 3 = 15 <= 16: ONE v_mfma_f32_32x32x16_bf16 per 32 queries x 32 targets, every
+// product exact in fp32, fp32 accumulation, two v_min3_f32 per 256 pairs.
 //
 // Geometry.  Targets are Morton-sorted once per call (the target does not move during the
 // ICP loop) and cut into splits of 2048; every split has its own centre c_s and radius
-// rho_s, and both operands of a (query block, split) workgroup are expressed about c_s.
-// The fp32 error of a pair is then ~80 u (|p-c_s| + rho_s)^2: tiny for the splits near the
+// rho_s, and both operands of a (query block, split) workgroup are expressed about c_s, so
+// the representation error scales with (|p-c_s| + rho_s): small for the splits near the
 // query, and large only where the distance itself is large.  Lane l / register r of a wave
-// keeps the running minimum of query row (l>>4)*4+r against column l&15 of every tile: a
-// "slot" = 128 targets CONTIGUOUS in the sorted array (tile t, column c of split s is sorted
-// position s*2048 + c*128 + t).  No index is tracked in the loop: the VALU work per MFMA is
-// two v_min3_f32.  The epilogue transposes through LDS to lane-per-query, adds |P|^2 and
-// writes either (column-tagged min, second min) [1-NN] or all 16 column minima [k-NN].
+// keeps the running minimum of query row (r&3)+8(r>>2)+4(l>>5) against column l&31 of every
+// tile: a "slot" = 64 targets CONTIGUOUS in the sorted array (tile t, column c of split s is
+// sorted position s*2048 + c*64 + t).  No index is tracked in the loop.  The epilogue
+// transposes through LDS, adds |P|^2 and writes either (column-tagged min, second min)
+// [1-NN] or all 32 column minima [k-NN] per (query, split).
 //
 // Resolve (k_nn_resolve / k_knn_resolve), fp64 in the reference's operation order: exact
 // scan of the winning slot -> D; every target with exact distance <= D has a coarse value
@@ -29,13 +32,15 @@
 // split's tau_s is scanned exactly too.  Result: exact minimum, ties to the lowest ORIGINAL
 // index -- bit-identical to k_nn_f64 and to the oracle.
 //
-// Error bound E_s(d) for a pair in split s.  u = 2^-24, a >= |p-c_s| + rho_s.
-//   coordinate rounding to fp32: eps (2 sqrt(d) + eps), eps = u a (1 + 1e-6)
-//   arithmetic: the 30 products are exact; their fp32 accumulation inside the MFMA is not
-//     specified, so every one of the <= 33 additions is charged a full truncation
-//     (2u x the largest magnitude, <= a^2): 66 u a^2; plus fl32(|Q|^2), fl32(|P|^2) formed
-//     with 5 roundings, and the final add: 73 u a^2.  80 u a^2 is used.
-//   column tag: < 2^-20 relative on the stored minimum (inflation 4e-6 covers it).
+// Error bound E_s(d) for a pair in split s.  a >= |p-c_s| + rho_s, u = 2^-24.
+//   representation: each centred coordinate is off by <= (2^-16 + 2^-24)|x| (fp32 rounding,
+//     then two bf16 pieces), so with eps = (2^-16 + 2^-24) a (1 + 1e-6):
+//     | |P-Q|^2 - |p-q|^2 | <= eps (2 sqrt(d) + eps)
+//   arithmetic: the 15 products are exact; their fp32 accumulation inside the MFMA is not
+//     specified, so every one of the <= 17 additions is charged a full truncation
+//     (2u x the largest magnitude, <= a^2): 34 u a^2; plus fl32(|Q|^2), fl32(|P|^2) formed
+//     with 5 roundings, and the final add: 41 u a^2.  48 u a^2 is used.
+//   column tag: < 2^-19 relative on the stored minimum (inflation 4e-6 covers it).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,20 +49,24 @@
 
 namespace icpmi {
 
-constexpr int kSplitTiles = 128;                  // target tiles (16 targets each) per split
-constexpr int kSplitTargets = kSplitTiles * 16;   // 2048
-constexpr int kSlotTargets = kSplitTiles;         // targets per (split, column) slot
+constexpr int kTile = 32;                         // queries / targets per MFMA tile
+constexpr int kCols = 32;                         // columns (slots) per split
+constexpr int kSplitTiles = 64;                   // target tiles per split
+constexpr int kSplitTargets = kSplitTiles * kTile;// 2048
+constexpr int kSlotTargets = kSplitTiles;         // 64 targets per (split, column) slot
 constexpr int kChunkTiles = 32;                   // tiles staged in LDS at a time (32 KiB)
-constexpr int kCoarseQT = 4;                      // query tiles per wave
+constexpr int kCoarseQT = 2;                      // 32-query tiles per wave (2 or 4)
 constexpr int kCoarseWaves = 8;                   // waves per workgroup
 constexpr int kCoarseVar = 0;                     // default scheduling variant (see k_nn_coarse)
 constexpr int kCoarseThreads = 64 * kCoarseWaves;
-constexpr int kCoarseQueries = 16 * kCoarseQT * kCoarseWaves; // queries per workgroup
+constexpr int kCoarseQueries = kTile * kCoarseQT * kCoarseWaves; // queries per workgroup
 constexpr float kBig = 3.0e38f;
-constexpr double kArithBound = 80.0;              // x u a^2, see above
+constexpr double kArithBound = 48.0;              // x u a^2, see above
+constexpr double kReprEps = 1.52587890625e-05 + 5.9604644775390625e-08; // 2^-16 + 2^-24
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct NnFrame {     // bounding box of the whole target (Morton quantisation)
     double lo[3], hi[3];
@@ -213,7 +222,8 @@ __global__ __launch_bounds__(256) void k_split_frames(const double *__restrict__
     }
 }
 
-// ---- exact three-way bf16 split of an fp32 value: x == h + m + l --------------------------------
+// ---- bf16 pieces of an fp32 value -----------------------------------------------------------------
+// exact three-way split: x == h + m + l
 __device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsigned &l)
 {
     const unsigned bh = __float_as_uint(x) & 0xFFFF0000u;
@@ -224,43 +234,53 @@ __device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsign
     m = bm >> 16;
     l = __float_as_uint(r2) >> 16;
 }
+// two-way split, second piece rounded to nearest even: |x - (h + m)| <= 2^-16 |x|
+__device__ __forceinline__ void split2(float x, unsigned &h, unsigned &m)
+{
+    const unsigned bh = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(bh); // exact
+    const unsigned b1 = __float_as_uint(r1);
+    h = bh >> 16;
+    m = (b1 + 0x7FFFu + ((b1 >> 16) & 1u)) >> 16;
+}
 
-// K-slot k of the contraction: A side (query) piece index, B side (target) piece index
-//   k = 9*axis + 3*i + j (k < 27): A = P_axis piece i, B = -2 * Q_axis piece j
-//   k = 27..29: A = 1, B = piece (k-27) of fl32(|Q|^2);  k = 30, 31: both 0
+// K-slot k of the contraction (K = 16):
+//   k = 4*axis + 2*i + j (k < 12): A = P_axis piece i, B = -2 * Q_axis piece j
+//   k = 12..14: A = 1, B = piece (k-12) of fl32(|Q|^2);  k = 15: both 0
 
-// ---- targets -> bf16 B operands: Bpack[(s*128 + t)*64 + lane] = 8 bf16 (k = 8*(lane>>4)+j) ----------
+// ---- targets -> bf16 B operands: Bpack[(s*64 + t)*64 + lane] = 8 bf16 (k = 8*(lane>>5)+e) ----------
+// tile t, column c = lane&31 of split s is sorted position s*2048 + c*64 + t
 __global__ __launch_bounds__(256) void k_pack_targets(const double *__restrict__ sorted, int m, int ms,
                                                       const SplitFrame *__restrict__ frames,
                                                       uint4 *__restrict__ Bpack, int splits)
 {
     const int gidx = blockIdx.x * 256 + threadIdx.x;
     if (gidx >= splits * kSplitTiles * 64) return;
-    const int lane = gidx & 63, t = (gidx >> 6) & (kSplitTiles - 1), s = gidx >> 13;
-    const int col = lane & 15, g = lane >> 4;
+    const int lane = gidx & 63, t = (gidx >> 6) & (kSplitTiles - 1), s = gidx / (kSplitTiles * 64);
+    const int col = lane & 31, half = lane >> 5;
     const long j = (long)s * kSplitTargets + col * kSlotTargets + t;
-    unsigned piece[3][3], np[3];
+    unsigned piece[3][2], np[3];
     if (j < m) {
         double n2 = 0.0;
         for (int a = 0; a < 3; ++a) {
             const float q = (float)(sorted[(size_t)a * ms + j] - frames[s].c[a]);
-            split3(q, piece[a][0], piece[a][1], piece[a][2]);
+            split2(q, piece[a][0], piece[a][1]);
             n2 += (double)q * (double)q;
         }
         split3((float)n2, np[0], np[1], np[2]);
     } else { // padding: never the minimum
-        for (int a = 0; a < 3; ++a) piece[a][0] = piece[a][1] = piece[a][2] = 0u;
+        for (int a = 0; a < 3; ++a) piece[a][0] = piece[a][1] = 0u;
         split3(kBig, np[0], np[1], np[2]);
     }
     unsigned w[8];
     for (int e = 0; e < 8; ++e) {
-        const int k = 8 * g + e;
+        const int k = 8 * half + e;
         unsigned v = 0u;
-        if (k < 27) {
-            const unsigned b = piece[k / 9][k % 3];
+        if (k < 12) {
+            const unsigned b = piece[k >> 2][k & 1];
             v = __float_as_uint(-2.0f * __uint_as_float(b << 16)) >> 16; // exact
-        } else if (k < 30) {
-            v = np[k - 27];
+        } else if (k < 15) {
+            v = np[k - 12];
         }
         w[e] = v & 0xFFFFu;
     }
@@ -273,161 +293,139 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
     return __builtin_fminf(__builtin_fminf(a, b), c); // -> v_min3_f32
 }
 
-// MODE 0: 1-NN epilogue -> coarse[split][n] = (tagged min, second min over columns)
-// MODE 1: k-NN epilogue  -> slotmin[query][split*16 + column], every column minimum kept
-// QT = query tiles (16 queries) per wave, a multiple of 4; WAVES = waves per workgroup.
-// VAR bit 0: software-pipeline the min3 one query tile behind its MFMAs; bit 1: keep the
-// next B chunk in flight in registers while the current one is consumed.
+// MODE 0: 1-NN epilogue -> coarse[split][n] = (tagged min, second min over the 32 columns)
+// MODE 1: k-NN epilogue  -> slotmin[query][split*32 + column], every column minimum kept
+// QT = 32-query tiles per wave (2 or 4); WAVES = waves per workgroup; VAR bit 0: the min3
+// of a tile is issued one tile behind its MFMAs (software pipeline).
 template <int MODE, int QT, int WAVES, int VAR>
 __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     const double *__restrict__ qry, int n, const uint4 *__restrict__ Bpack,
     const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/,
-    float *__restrict__ slotmin /*[n][splits*16]*/, const IcpState *__restrict__ st)
+    float *__restrict__ slotmin /*[n][splits*32]*/, const IcpState *__restrict__ st)
 {
-    static_assert(QT % 4 == 0, "operands and epilogue work on groups of 64 queries");
+    static_assert(QT % 2 == 0, "operands are staged 64 queries at a time");
     constexpr int THREADS = 64 * WAVES;
-    constexpr int CHUNK16 = kChunkTiles * 64; // uint4 per staged chunk (32 KiB)
-    constexpr int SCRATCH16 = WAVES * 64 * 20 / 4 > CHUNK16 ? WAVES * 64 * 20 / 4 : CHUNK16;
-    static_assert(WAVES * 64 * 4 <= CHUNK16, "A staging fits the chunk buffer");
+    constexpr int CHUNK16 = kChunkTiles * 64;  // uint4 per staged chunk (32 KiB)
+    constexpr int EPI16 = 32 * 36 / 4;         // uint4 per wave for the epilogue transpose
+    constexpr int SCRATCH16 = WAVES * EPI16 > CHUNK16 ? WAVES * EPI16 : CHUNK16;
+    constexpr bool PIPE = VAR & 1;
     if (st && st->done) return;
     __shared__ uint4 lds[SCRATCH16];
     const int s = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q0 = (blockIdx.x * WAVES + wave) * (16 * QT);
+    const int q0 = (blockIdx.x * WAVES + wave) * (kTile * QT);
     const double c0 = frames[s].c[0], c1 = frames[s].c[1], c2 = frames[s].c[2];
 
-    // A operands.  Each lane builds the 32-slot bf16 row of ONE query (lane-per-query:
+    // A operands.  Each lane builds the 16-slot bf16 row of ONE query (lane-per-query:
     // coalesced fp64 loads, pieces computed once), rows go through LDS, and every lane
-    // picks up its fragment: row l&15 of the tile, slots 8*(l>>4) .. +7.
+    // picks up its fragment: row l&31 of the tile, slots 8*(l>>5) .. +7.
     bf16x8 afrag[QT];
-    float pn[QT / 4];
+    float pn[QT / 2];
     {
-        uint4 *rows = lds + wave * (64 * 4); // 64 rows x 64 B
+        uint4 *rows = lds + wave * (64 * 2); // 64 rows x 32 B
 #pragma unroll
-        for (int gq = 0; gq < QT / 4; ++gq) {
+        for (int gq = 0; gq < QT / 2; ++gq) {
             const int iq = q0 + gq * 64 + lane < n ? q0 + gq * 64 + lane : n - 1;
             const float px = (float)(qry[3 * iq] - c0), py = (float)(qry[3 * iq + 1] - c1),
                         pz = (float)(qry[3 * iq + 2] - c2);
             pn[gq] = (px * px + py * py) + pz * pz;
-            unsigned xh, xm, xl, yh, ym, yl, zh, zm, zl;
-            split3(px, xh, xm, xl);
-            split3(py, yh, ym, yl);
-            split3(pz, zh, zm, zl);
+            unsigned xh, xm, yh, ym, zh, zm;
+            split2(px, xh, xm);
+            split2(py, yh, ym);
+            split2(pz, zh, zm);
             const unsigned one = 0x3f80u;
-            // slots: x: h h h m m m l l | l, y: h h h m m m l | l l, z: h h h m m m | l l l 1 1 1 0 0
-            rows[lane * 4 + 0] = make_uint4(xh | (xh << 16), xh | (xm << 16), xm | (xm << 16), xl | (xl << 16));
-            rows[lane * 4 + 1] = make_uint4(xl | (yh << 16), yh | (yh << 16), ym | (ym << 16), ym | (yl << 16));
-            rows[lane * 4 + 2] = make_uint4(yl | (yl << 16), zh | (zh << 16), zh | (zm << 16), zm | (zm << 16));
-            rows[lane * 4 + 3] = make_uint4(zl | (zl << 16), zl | (one << 16), one | (one << 16), 0u);
+            // slots: x: h h m m, y: h h m m | z: h h m m, 1 1 1 0
+            rows[lane * 2 + 0] = make_uint4(xh | (xh << 16), xm | (xm << 16), yh | (yh << 16), ym | (ym << 16));
+            rows[lane * 2 + 1] = make_uint4(zh | (zh << 16), zm | (zm << 16), one | (one << 16), one);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint4 f = rows[(t * 16 + (lane & 15)) * 4 + (lane >> 4)];
-                afrag[gq * 4 + t] = __builtin_bit_cast(bf16x8, f);
+            for (int t = 0; t < 2; ++t) {
+                const uint4 f = rows[(t * 32 + (lane & 31)) * 2 + (lane >> 5)];
+                afrag[gq * 2 + t] = __builtin_bit_cast(bf16x8, f);
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
-    f32x4 m[QT];
+    f32x16 m[QT];
 #pragma unroll
-    for (int t = 0; t < QT; ++t) m[t] = (f32x4){kBig, kBig, kBig, kBig};
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[t][r] = kBig;
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+    f32x16 pa, pb; // PIPE: results whose min3 is still pending
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pa[r] = pb[r] = kBig;
 
-    // B operands: 4 chunks of 32 tiles through one 32 KiB LDS buffer
-    constexpr bool PIPE = VAR & 1, PREFETCH = VAR & 2;
+    // B operands: 2 chunks of 32 tiles through one 32 KiB LDS buffer
     const uint4 *src = Bpack + (size_t)s * (kSplitTiles * 64);
-    uint4 pre[CHUNK16 / THREADS];
-    if (PREFETCH) {
-#pragma unroll
-        for (int e = 0; e < CHUNK16 / THREADS; ++e) pre[e] = src[threadIdx.x + e * THREADS];
-    }
-    f32x4 p0 = {kBig, kBig, kBig, kBig}, p1 = p0; // PIPE: results whose min3 is still pending
 #pragma unroll 1
     for (int chunk = 0; chunk < kSplitTiles / kChunkTiles; ++chunk) {
         __syncthreads(); // A rows / previous chunk no longer needed
-        if (PREFETCH) {
 #pragma unroll
-            for (int e = 0; e < CHUNK16 / THREADS; ++e) lds[threadIdx.x + e * THREADS] = pre[e];
-            if (chunk + 1 < kSplitTiles / kChunkTiles) {
-#pragma unroll
-                for (int e = 0; e < CHUNK16 / THREADS; ++e)
-                    pre[e] = src[(size_t)(chunk + 1) * CHUNK16 + threadIdx.x + e * THREADS];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < CHUNK16 / THREADS; ++e)
-                lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
-        }
-        if (PREFETCH) {
-            // wait for the LDS stores only: __syncthreads() would also drain vmcnt and with
-            // it the prefetch that was just issued
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        } else {
-            __syncthreads();
-        }
-#pragma unroll 2
+        for (int e = 0; e < CHUNK16 / THREADS; ++e)
+            lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
+        __syncthreads();
+#pragma unroll 1
         for (int tt = 0; tt < kChunkTiles; tt += 2) {
             const bf16x8 b0 = __builtin_bit_cast(bf16x8, lds[tt * 64 + lane]);
             const bf16x8 b1 = __builtin_bit_cast(bf16x8, lds[(tt + 1) * 64 + lane]);
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t], b0, zero, 0, 0, 0);
-                const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[t], b1, zero, 0, 0, 0);
+                const f32x16 da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[t], b0, zero, 0, 0, 0);
+                const f32x16 db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[t], b1, zero, 0, 0, 0);
                 if (PIPE) {
-                    // the two MFMAs above go out first; the VALU work is the PREVIOUS tile's,
-                    // whose results are already back (no wait states needed)
-                    constexpr int dummy = 0;
-                    (void)dummy;
                     const int tp = (t + QT - 1) % QT;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) m[tp][r] = min3f(m[tp][r], p0[r], p1[r]);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    p0 = d0;
-                    p1 = d1;
+                    for (int r = 0; r < 16; ++r) m[tp][r] = min3f(m[tp][r], pa[r], pb[r]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    pa = da;
+                    pb = db;
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) m[t][r] = min3f(m[t][r], d0[r], d1[r]);
+                    for (int r = 0; r < 16; ++r) m[t][r] = min3f(m[t][r], da[r], db[r]);
                 }
             }
         }
     }
     if (PIPE) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m[QT - 1][r] = min3f(m[QT - 1][r], p0[r], p1[r]);
+        for (int r = 0; r < 16; ++r) m[QT - 1][r] = min3f(m[QT - 1][r], pa[r], pb[r]);
     }
 
-    // epilogue.  Transpose through LDS, 64 queries at a time, so that each lane owns ONE
-    // query and its 16 column minima (row stride 20 floats: conflict-free ds_read_b128),
-    // then + |P|^2 and either the tagged (min, second min) pair or the raw 16 values go
-    // out, coalesced.
+    // epilogue.  Transpose through LDS, one 32-query tile at a time (row stride 36 floats:
+    // conflict-free ds_read_b128): lane l then owns query l&31 and columns 16*(l>>5).. +15;
+    // + |P|^2, per-lane top-2, the two halves merge with one cross-lane step.
     __syncthreads(); // every wave is done with the B operands
-    float *sc = reinterpret_cast<float *>(lds) + wave * (64 * 20);
-    const int g = lane >> 4, col = lane & 15;
+    float *sc = reinterpret_cast<float *>(lds) + wave * (32 * 36);
+    const int ql = lane & 31, half = lane >> 5;
 #pragma unroll
-    for (int gq = 0; gq < QT / 4; ++gq) {
+    for (int t = 0; t < QT; ++t) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[(t * 16 + g * 4 + r) * 20 + col] = m[gq * 4 + t][r];
+        for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + ql] = m[t][r];
         __builtin_amdgcn_wave_barrier();
         float v[16];
+        const float pnq = __shfl(pn[t >> 1], (t & 1) * 32 + ql, 64);
         {
-            const float4 *rowp = reinterpret_cast<const float4 *>(sc + lane * 20);
+            const float4 *rowp = reinterpret_cast<const float4 *>(sc + ql * 36 + half * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float4 x = rowp[e];
-                v[4 * e] = x.x + pn[gq];
-                v[4 * e + 1] = x.y + pn[gq];
-                v[4 * e + 2] = x.z + pn[gq];
-                v[4 * e + 3] = x.w + pn[gq];
+                v[4 * e] = x.x + pnq;
+                v[4 * e + 1] = x.y + pnq;
+                v[4 * e + 2] = x.z + pnq;
+                v[4 * e + 3] = x.w + pnq;
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const int iq = q0 + gq * 64 + lane;
+        const int iq = q0 + t * 32 + ql;
         if (MODE == 1) {
             if (iq < n) {
-                float4 *dst = reinterpret_cast<float4 *>(slotmin + (size_t)iq * (gridDim.y * 16) + s * 16);
+                float4 *dst = reinterpret_cast<float4 *>(slotmin + (size_t)iq * (gridDim.y * kCols) + s * kCols + half * 16);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dst[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
             }
@@ -435,12 +433,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
             float v1 = kBig, v2 = kBig;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const float x = __uint_as_float((__float_as_uint(v[c]) & 0xFFFFFFF0u) | (unsigned)c);
+                const float x = __uint_as_float((__float_as_uint(v[c]) & 0xFFFFFFE0u) | (unsigned)(half * 16 + c));
                 const float hi = __builtin_fmaxf(v1, x);
                 v1 = __builtin_fminf(v1, x);
                 v2 = __builtin_fminf(v2, hi);
             }
-            if (iq < n) coarse[(size_t)s * n + iq] = make_float2(v1, v2);
+            const float o1 = __shfl_xor(v1, 32, 64), o2 = __shfl_xor(v2, 32, 64);
+            const float hi = __builtin_fmaxf(v1, o1);
+            v1 = __builtin_fminf(v1, o1);
+            v2 = min3f(hi, v2, o2);
+            if (half == 0 && iq < n) coarse[(size_t)s * n + iq] = make_float2(v1, v2);
         }
     }
 }
@@ -453,7 +455,7 @@ __device__ __forceinline__ float split_tau(double px, double py, double pz, cons
     const double dx = px - f.c[0], dy = py - f.c[1], dz = pz - f.c[2];
     const double a = sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + f.rho;
     const double u = 5.9604644775390625e-08; // 2^-24
-    const double eps = u * a * (1.0 + 1e-6);
+    const double eps = kReprEps * a * (1.0 + 1e-6);
     double tau = d + eps * (2.0 * sqrt_d + eps) + kArithBound * u * a * a;
     tau = tau * (1.0 + 4e-6) + 1e-300; // column tag (2^-20) + slack for this fp64 evaluation
     return __uint_as_float(__float_as_uint((float)tau) + 1u); // round up (tau > 0)
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
             bs = os;
         }
     }
-    const int bcol = (int)(__float_as_uint(best) & 15u);
+    const int bcol = (int)(__float_as_uint(best) & 31u);
 
     // phase 2: exact evaluation of the winning slots, one query per quarter-wave and round
     double bd = 1.7976931348623157e308;
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
         double d = 1.7976931348623157e308;
         int j = 0x7fffffff;
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
+        for (int o = 0; o < kSlotTargets / 16; ++o) {
             const int jj = j0 + 16 * o;
             const int jc = jj < m ? jj : m - 1;
             const double dd = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), qx, qy, qz);
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
             pend &= pend - 1;
             const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
             const int w = __shfl((int)whole, L, 64);
-            const int c = __shfl((int)(__float_as_uint(v.x) & 15u), L, 64);
+            const int c = __shfl((int)(__float_as_uint(v.x) & 31u), L, 64);
             const int sL = s0 + (L >> 4);
             double d = 1.7976931348623157e308;
             int j = 0x7fffffff;
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     const int bslot = __shfl(lslot, __ffsll((long long)__ballot(rank == 0)) - 1, 64);
     double a;
     {
-        const SplitFrame &f = frames[lslot >> 4];
+        const SplitFrame &f = frames[lslot / kCols];
         const double dx = px - f.c[0], dy = py - f.c[1], dz = pz - f.c[2];
         a = rank < kk ? sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + f.rho : 0.0;
 #pragma unroll
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         }
     }
     const double u = 5.9604644775390625e-08;
-    const double eps = u * a * (1.0 + 1e-6);
+    const double eps = kReprEps * a * (1.0 + 1e-6);
     const double A = kArithBound * u * a * a;
     const double ts = tS > 0.f ? (double)tS * (1.0 + 1e-6) : 0.0;
     const double xr = eps + sqrt(eps * eps + (ts + eps * eps + A)); // sqrt(dmax)
@@ -729,7 +731,9 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     double d0 = kInf, d1 = kInf;
     int o0 = 0, o1 = 0;
     {
-        const int j0 = (bslot >> 4) * kSplitTargets + (bslot & 15) * kSlotTargets;
+        // the best slot (64 targets, one per lane) and the 64 sorted positions after it (the next
+        // slot: only used to tighten the bound, collected later through the normal path)
+        const int j0 = (bslot / kCols) * kSplitTargets + (bslot % kCols) * kSlotTargets;
         const int ja = j0 + lane, jb = j0 + 64 + lane;
         if (ja < m) {
             d0 = sqdist(ICPMI_SX(sorted, ms, ja), ICPMI_SY(sorted, ms, ja), ICPMI_SZ(sorted, ms, ja), px, py, pz);
@@ -747,27 +751,21 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     // candidates: the best slot's targets under T, then every other slot under its split's bound
     int total = 0;
     {
-        const bool k0 = d0 <= T, k1 = d1 <= T;
-        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-        const unsigned long long below = (1ull << lane) - 1ull;
+        const bool k0 = d0 <= T;
+        const unsigned long long m0 = __ballot(k0);
         if (k0) {
-            const int pos = __popcll(m0 & below);
-            cand_d[wave][pos] = d0; // at most 128 <= kKnnCap
+            const int pos = __popcll(m0 & ((1ull << lane) - 1ull));
+            cand_d[wave][pos] = d0; // at most 64 <= kKnnCap
             cand_j[wave][pos] = o0;
         }
         total = __popcll(m0);
-        if (k1) {
-            const int pos = total + __popcll(m1 & below);
-            cand_d[wave][pos] = d1;
-            cand_j[wave][pos] = o1;
-        }
-        total += __popcll(m1);
     }
+    (void)o1;
     for (int e0 = 0; e0 < nslots; e0 += 64) {
         const int e = e0 + lane;
         bool flag = false;
         if (e < nslots && e != bslot) {
-            const float tauf = T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[e >> 4], T, sq);
+            const float tauf = T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[e / kCols], T, sq);
             flag = mine[e] <= tauf;
         }
         unsigned long long pend = __ballot(flag);
@@ -775,7 +773,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             const int L = __ffsll((long long)pend) - 1;
             pend &= pend - 1;
             const int se = e0 + L;
-            const int j0 = (se >> 4) * kSplitTargets + (se & 15) * kSlotTargets;
+            const int j0 = (se / kCols) * kSplitTargets + (se % kCols) * kSlotTargets;
 #pragma unroll
             for (int o = 0; o < kSlotTargets; o += 64) {
                 const int jj = j0 + o + lane;
