@@ -34,8 +34,9 @@
 //
 // Error bound E_s(d) for a pair in split s.  a >= |p-c_s| + rho_s, u = 2^-24.
 //   representation: each centred coordinate is off by <= (2^-16 + 2^-24)|x| (fp32 rounding,
-//     then two bf16 pieces), so with eps = (2^-16 + 2^-24) a (1 + 1e-6):
-//     | |P-Q|^2 - |p-q|^2 | <= eps (2 sqrt(d) + eps)
+//     then two bf16 pieces); BOTH norms are those of the represented points, so the
+//     contraction is |P~ - Q~|^2 of two slightly moved points and, with
+//     eps = (2^-16 + 2^-24) a (1 + 1e-6):   | |P~-Q~|^2 - |p-q|^2 | <= eps (2 sqrt(d) + eps)
 //   arithmetic: the 15 products are exact; their fp32 accumulation inside the MFMA is not
 //     specified, so every one of the <= 17 additions is charged a full truncation
 //     (2u x the largest magnitude, <= a^2): 34 u a^2; plus fl32(|Q|^2), fl32(|P|^2) formed
@@ -265,7 +266,10 @@ __global__ __launch_bounds__(256) void k_pack_targets(const double *__restrict__
         for (int a = 0; a < 3; ++a) {
             const float q = (float)(sorted[(size_t)a * ms + j] - frames[s].c[a]);
             split2(q, piece[a][0], piece[a][1]);
-            n2 += (double)q * (double)q;
+            // the norm must be that of the REPRESENTED point (h + m), or the cross-term error
+            // 2 (dP.Q + P.dQ) ~ 2^-16 a^2 would not cancel
+            const double qt = (double)__uint_as_float(piece[a][0] << 16) + (double)__uint_as_float(piece[a][1] << 16);
+            n2 += qt * qt;
         }
         split3((float)n2, np[0], np[1], np[2]);
     } else { // padding: never the minimum
@@ -328,11 +332,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
             const int iq = q0 + gq * 64 + lane < n ? q0 + gq * 64 + lane : n - 1;
             const float px = (float)(qry[3 * iq] - c0), py = (float)(qry[3 * iq + 1] - c1),
                         pz = (float)(qry[3 * iq + 2] - c2);
-            pn[gq] = (px * px + py * py) + pz * pz;
             unsigned xh, xm, yh, ym, zh, zm;
             split2(px, xh, xm);
             split2(py, yh, ym);
             split2(pz, zh, zm);
+            {   // |P|^2 of the REPRESENTED point (h + m: exact in fp32), see k_pack_targets
+                const float tx = __uint_as_float(xh << 16) + __uint_as_float(xm << 16);
+                const float ty = __uint_as_float(yh << 16) + __uint_as_float(ym << 16);
+                const float tz = __uint_as_float(zh << 16) + __uint_as_float(zm << 16);
+                pn[gq] = (tx * tx + ty * ty) + tz * tz;
+            }
             const unsigned one = 0x3f80u;
             // slots: x: h h m m, y: h h m m | z: h h m m, 1 1 1 0
             rows[lane * 2 + 0] = make_uint4(xh | (xh << 16), xm | (xm << 16), yh | (yh << 16), ym | (ym << 16));
