@@ -665,7 +665,8 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
 // their split's bound are scanned exactly (fp64, reference operation order) and every target
 // with exact distance <= T is collected; the k smallest by (distance, original index) are
 // written closest first -- the order kdtree.hpp:72-76 returns and icp.hpp:41-51 sums in.
-constexpr int kKnnCap = 512; // candidates per row held in LDS; overflow -> exact fallback list
+constexpr int kKnnCap = 512;        // candidates per row held in LDS
+constexpr int kKnnMaxSplits = 1024; // per-split bounds cached in LDS (2M targets); beyond: recomputed
 
 // k-th smallest (k = kk, 1-based) of one double per lane; DBL_MAX when fewer than kk are finite
 __device__ __forceinline__ double wave_kth_smallest(double v, int lane, int kk)
@@ -690,6 +691,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
 {
     __shared__ double cand_d[4][kKnnCap];
     __shared__ int cand_j[4][kKnnCap];
+    __shared__ float tau_sp[4][kKnnMaxSplits]; // per-split bound on the coarse value, per row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int local = blockIdx.x * 4 + wave;
     if (local >= nrows) return; // wave-uniform
@@ -754,54 +756,85 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         }
     }
     const double t1 = wave_kth_smallest(d0 < d1 ? d0 : d1, lane, kk);
-    const double T = t1 < dmax ? t1 : dmax;
-    const double sq = sqrt(T);
-
-    // candidates: the best slot's targets under T, then every other slot under its split's bound
-    int total = 0;
-    {
-        const bool k0 = d0 <= T;
-        const unsigned long long m0 = __ballot(k0);
-        if (k0) {
-            const int pos = __popcll(m0 & ((1ull << lane) - 1ull));
-            cand_d[wave][pos] = d0; // at most 64 <= kKnnCap
-            cand_j[wave][pos] = o0;
-        }
-        total = __popcll(m0);
-    }
+    double T = t1 < dmax ? t1 : dmax;
     (void)o1;
-    for (int e0 = 0; e0 < nslots; e0 += 64) {
-        const int e = e0 + lane;
-        bool flag = false;
-        if (e < nslots && e != bslot) {
-            const float tauf = T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[e / kCols], T, sq);
-            flag = mine[e] <= tauf;
+
+    // candidates: the best slot's targets under T, then every other slot under its split's
+    // bound.  If more than kKnnCap turn up, the k-th smallest of those already held is a
+    // tighter valid bound: collect again with it (a few rows per cloud).
+    const int nsplits = (nslots + kCols - 1) / kCols;
+    int total = 0;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        const double sq = sqrt(T);
+        for (int sp = lane; sp < nsplits && sp < kKnnMaxSplits; sp += 64)
+            tau_sp[wave][sp] = T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[sp], T, sq);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const bool k0 = d0 <= T;
+            const unsigned long long m0 = __ballot(k0);
+            if (k0) {
+                const int pos = __popcll(m0 & ((1ull << lane) - 1ull));
+                cand_d[wave][pos] = d0; // at most 64 <= kKnnCap
+                cand_j[wave][pos] = o0;
+            }
+            total = __popcll(m0);
         }
-        unsigned long long pend = __ballot(flag);
-        while (pend) {
-            const int L = __ffsll((long long)pend) - 1;
-            pend &= pend - 1;
-            const int se = e0 + L;
-            const int j0 = (se / kCols) * kSplitTargets + (se % kCols) * kSlotTargets;
+        for (int e0 = 0; e0 < nslots; e0 += 64) {
+            const int e = e0 + lane;
+            bool flag = false;
+            if (e < nslots && e != bslot) {
+                const int sp = e / kCols;
+                const float tauf = sp < kKnnMaxSplits ? tau_sp[wave][sp]
+                                                      : (T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[sp], T, sq));
+                flag = mine[e] <= tauf;
+            }
+            unsigned long long pend = __ballot(flag);
+            while (pend) {
+                const int L = __ffsll((long long)pend) - 1;
+                pend &= pend - 1;
+                const int se = e0 + L;
+                const int j0 = (se / kCols) * kSplitTargets + (se % kCols) * kSlotTargets;
 #pragma unroll
-            for (int o = 0; o < kSlotTargets; o += 64) {
-                const int jj = j0 + o + lane;
-                double d = kInf;
-                if (jj < m) d = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), px, py, pz);
-                const bool keep = d <= T;
-                const unsigned long long km = __ballot(keep);
-                if (keep) {
-                    const int pos = total + __popcll(km & ((1ull << lane) - 1ull));
-                    if (pos < kKnnCap) {
-                        cand_d[wave][pos] = d;
-                        cand_j[wave][pos] = (int)perm[jj];
+                for (int o = 0; o < kSlotTargets; o += 64) {
+                    const int jj = j0 + o + lane;
+                    double d = kInf;
+                    if (jj < m) d = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), px, py, pz);
+                    const bool keep = d <= T;
+                    const unsigned long long km = __ballot(keep);
+                    if (keep) {
+                        const int pos = total + __popcll(km & ((1ull << lane) - 1ull));
+                        if (pos < kKnnCap) {
+                            cand_d[wave][pos] = d;
+                            cand_j[wave][pos] = (int)perm[jj];
+                        }
                     }
+                    total += __popcll(km);
                 }
-                total += __popcll(km);
             }
         }
+        if (total <= kKnnCap) break;
+        // k-th smallest of the kKnnCap candidates held (all real targets): new bound
+        __builtin_amdgcn_wave_barrier();
+        double tnew = kInf;
+        for (int e = lane; e < kKnnCap; e += 64) {
+            const double d = cand_d[wave][e];
+            int r = 0;
+            for (int f = 0; f < kKnnCap; ++f) {
+                const double df = cand_d[wave][f];
+                r += (df < d || (df == d && f < e)) ? 1 : 0;
+            }
+            if (r == kk - 1) tnew = d;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(tnew, off, 64);
+            tnew = o < tnew ? o : tnew;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!(tnew < T)) break; // cannot tighten (e.g. hundreds of coincident points)
+        T = tnew;
     }
-    if (total > kKnnCap) { // too many targets under the bound: hand the row to the exact kernel
+    if (total > kKnnCap) { // still too many targets under the bound: hand the row to the exact kernel
         if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = i;
         return;
     }

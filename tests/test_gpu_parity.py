@@ -114,6 +114,16 @@ def test_normals_candidate_overflow_falls_back_exactly(gpu_ctx, oracle):
     assert (got[8700:] == [1.0, 0.0, 0.0]).all()  # zero covariance -> first axis
 
 
+def test_normals_more_coincident_points_than_the_candidate_list(gpu_ctx, oracle):
+    """700 coincident points: the in-kernel bound cannot be tightened below 0, the rows go to
+    the exact workgroup-per-row kernel."""
+    rng = np.random.default_rng(13)
+    pts = np.concatenate([rng.uniform(-20, 20, (8700, 3)), np.tile([[1.5, -2.5, 0.25]], (700, 1))])
+    got = gpu_ctx.estimate_normals(pts, 20)
+    want = oracle.estimate_normals(pts, None, 20, nthreads=4)
+    assert (got == want).all()
+
+
 def test_normals_few_points(gpu_ctx):
     tgt = np.array([[0.0, 0, 0], [1, 0, 0]])
     assert (gpu_ctx.estimate_normals(tgt, 20) == [[0, 0, 1], [0, 0, 1]]).all()  # icp.hpp:34-37
@@ -312,6 +322,32 @@ def test_mfma_engine_certificate_paths(gpu_ctx, oracle):
         gpu_ctx.nearest_batch(tgt, qry)
         p = gpu_ctx.get_profile()
         assert p["nn_recheck_queries"] + p["nn_fallback_queries"] > 0  # the branches ran
+
+
+@pytest.mark.parametrize("scale,offset,seed", [(1.0, 0.0, 1), (100.0, 0.0, 2), (0.01, 0.0, 3),
+                                               (1.0, 1.0e4, 4), (30.0, -2.5e3, 5)])
+def test_mfma_engine_near_ties_across_scales(gpu_ctx, oracle, scale, offset, seed):
+    """The certificate's error bound must hold whatever the cloud's size and position:
+    clustered targets, queries whose two best candidates differ by ~1e-9 relative, all at
+    different scales and far from the origin."""
+    rng = np.random.default_rng(seed)
+    m, nq = 9000, 1500
+    centers = rng.uniform(-40, 40, (60, 3))
+    tgt = centers[rng.integers(0, 60, m)] + rng.normal(0, 1.5, (m, 3))
+    qry = tgt[rng.integers(0, m, nq)] + rng.normal(0, 0.3, (nq, 3))
+    # plant pairs of targets at (almost) the same distance from the first 400 queries
+    for q in range(400):
+        d = rng.normal(size=(2, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        r = 0.02 * (1.0 + np.array([0.0, 1e-9 * rng.uniform(-1, 1)]))
+        tgt[rng.choice(m, 2, replace=False)] = qry[q] + d * r[:, None]
+    tgt = tgt * scale + offset
+    qry = qry * scale + offset
+    idx, d2 = gpu_ctx.nearest_batch(tgt, qry)
+    oidx, od2 = oracle.nearest_batch_brute(tgt, qry)
+    assert (idx == oidx).all() and (d2 == od2).all()
+    nrm = gpu_ctx.estimate_normals(tgt, 20)
+    assert (nrm == oracle.estimate_normals(tgt, None, 20, nthreads=4)).all()
 
 
 def test_mfma_engine_exact_ties(gpu_ctx, oracle):
