@@ -75,7 +75,8 @@ typedef struct {
 /* per-stage device time from HIP events on the library's stream, accumulated since
  * the last icpmi_reset_profile(); only filled when options.profile != 0 */
 typedef struct {
-    double nn_ms;        int64_t nn_launches;        /* correspondence search passes */
+    double nn_ms;        int64_t nn_launches;        /* correspondence search passes (coarse + resolve) */
+    double coarse_ms;    int64_t coarse_launches;    /* k_nn_coarse alone: the dominant kernel */
     double reduce_ms;    int64_t reduce_launches;    /* residual + 6x6 accumulation + solve */
     double transform_ms; int64_t transform_launches;
     double normals_ms;   int64_t normals_launches;   /* k-NN + PCA */

@@ -45,6 +45,7 @@ class Result(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [("nn_ms", C.c_double), ("nn_launches", C.c_int64),
+                ("coarse_ms", C.c_double), ("coarse_launches", C.c_int64),
                 ("reduce_ms", C.c_double), ("reduce_launches", C.c_int64),
                 ("transform_ms", C.c_double), ("transform_launches", C.c_int64),
                 ("normals_ms", C.c_double), ("normals_launches", C.c_int64),
