@@ -85,7 +85,8 @@ def main():
     d_tgt = torch.from_numpy(tgt).to(dev)
     torch.cuda.synchronize()
 
-    ctx = capi.Context(device=local_rank, search=args.search, profile=True)
+    # profile level 1: HIP events around the dominant kernel and the call/loop only
+    ctx = capi.Context(device=local_rank, search=args.search, profile=1)
     if world > 1:
         icpdist.init_rccl(ctx, dist, device=dev)
 
@@ -113,13 +114,22 @@ def main():
         elapsed = float(t.item())
     prof = ctx.get_profile()
     assert res.loop_iterations == args.steps, (res.loop_iterations, args.steps)
+    # per-stage breakdown from a second, untimed call with every stage bracketed by events
+    ctx.close()
+    ctx = capi.Context(device=local_rank, search=args.search, profile=2)
+    if world > 1:
+        icpdist.init_rccl(ctx, dist, device=dev)
+    call(args.steps)
+    ctx.reset_profile()
+    call(args.steps)
+    stage = ctx.get_profile()
 
     if rank == 0:
         n_local, m = hi - lo, tgt.shape[0]
         mfma = prof["coarse_launches"] > 0
         # dominant kernel: k_nn_coarse (bf16 MFMA engine) or the whole fp64 pass (exact engine)
-        k_ms = prof["coarse_ms"] / prof["coarse_launches"] if mfma else prof["nn_ms"] / max(prof["nn_launches"], 1)
-        nn_avg_ms = prof["nn_ms"] / max(prof["nn_launches"], 1)
+        k_ms = prof["coarse_ms"] / prof["coarse_launches"] if mfma else stage["nn_ms"] / max(stage["nn_launches"], 1)
+        nn_avg_ms = stage["nn_ms"] / max(stage["nn_launches"], 1)
         flops = FLOP_PER_PAIR * n_local * m
         achieved = flops / (k_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if mfma else PEAK_FP32_TFLOPS
@@ -150,9 +160,9 @@ def main():
                        "search": "bf16 MFMA coarse pass over all pairs + certified fp64 resolve" if mfma
                        else "exact fp64 brute force"},
             "steady_state_it_per_s": (args.steps + 1) / (prof["loop_ms"] * 1e-3) if prof["loop_ms"] > 0 else None,
-            "stage_ms": {k: prof[k] for k in ("nn_ms", "coarse_ms", "reduce_ms", "transform_ms", "normals_ms",
-                                              "setup_ms", "loop_ms", "total_ms")},
-            "resolve_counters": {k: prof[k] for k in ("nn_recheck_queries", "nn_fallback_queries", "knn_fallback_rows")},
+            "stage_ms_untimed_call": {k: stage[k] for k in ("nn_ms", "coarse_ms", "reduce_ms", "transform_ms",
+                                                            "normals_ms", "setup_ms", "loop_ms", "total_ms")},
+            "resolve_counters": {k: stage[k] for k in ("nn_recheck_queries", "nn_fallback_queries", "knn_fallback_rows")},
             "final_error": res.final_error,
             "roofline": {
                 "kernel": "k_nn_coarse (bf16 MFMA, all %dx%d pairs)" % (n_local, m) if mfma else "k_nn_f64",

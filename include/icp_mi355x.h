@@ -50,7 +50,8 @@ typedef struct {
     int32_t device;     /* HIP device ordinal */
     int32_t normal_k;   /* neighbours for PCA normals; the reference hard-codes 20 (icp.hpp:170) */
     int32_t search;     /* ICPMI_SEARCH_* */
-    int32_t profile;    /* non-zero: bracket kernels with HIP events (icpmi_get_profile) */
+    int32_t profile;    /* 0 off; 1: HIP events around the dominant kernel and the call/loop;
+                           2: around every stage (icpmi_get_profile) */
 } icpmi_options;
 
 /* mirrors slam::ICPConfig, types.hpp:143-148 */

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -76,8 +77,8 @@ struct icpmi_ctx {
     int nn_ms = 0;                            // component stride of the SoA sorted target
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
-    int32_t *h_flags = nullptr;    // pinned ring of done flags
-    std::vector<hipEvent_t> flag_events;
+    int32_t *h_flags = nullptr;    // host-mapped ring: (iteration + 1) * 2 + done, written by the device
+    int32_t *d_flags = nullptr;    // the same words through the device's address space
 
     // profiling
     std::vector<EventPair> ev_pool;
@@ -145,7 +146,10 @@ struct StageTimer {
     long slot = -1; // index, not pointer: the pool may reallocate while an outer timer is open
     StageTimer(icpmi_ctx *c, int stage) : ctx(c)
     {
+        // profile 1: only the dominant kernel and the call/loop brackets (3 event pairs per
+        // iteration would already cost ~10 us of stream time); profile >= 2: every stage
         if (!ctx->opt.profile) return;
+        if (ctx->opt.profile == 1 && stage != ST_COARSE && stage != ST_TOTAL && stage != ST_LOOP) return;
         if (ctx->ev_used == ctx->ev_pool.size()) {
             EventPair p;
             if (hipEventCreate(&p.a) != hipSuccess) return;
@@ -500,7 +504,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                            cur, n, ctx->d_state, 1, 0);
     }
 
-    auto iteration = [&](int final_pass) -> int {
+    auto iteration = [&](int final_pass, int *progress, int ticket) -> int {
         int r2;
         if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, ctx->d_state))) return r2;
         {
@@ -511,10 +515,10 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, partials, rblocks, n,
                                    ctx->d_state);
                 if ((r2 = exchange_allreduce(ctx, ctx->d_state->sums, kNumSums))) return r2;
-                hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, ctx->d_state, hist, final_pass);
+                hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, ctx->d_state, hist, final_pass, progress, ticket);
             } else {
                 hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(256), 0, s, partials, rblocks, n,
-                                   ctx->d_state, hist, final_pass);
+                                   ctx->d_state, hist, final_pass, progress, ticket);
             }
         }
         if (!final_pass) {
@@ -527,21 +531,30 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
 
     StageTimer *t_loop = new StageTimer(ctx, ST_LOOP);
     struct Closer2 { StageTimer *&p; ~Closer2() { delete p; p = nullptr; } } close_loop{t_loop};
+    for (int i = 0; i < kFlagRing; ++i) ctx->h_flags[i] = 0;
     for (int it = 0; it < max_it; ++it) {
         if (it >= kLag) {
-            const int slot = (it - kLag) % kFlagRing;
-            HIP_TRY(ctx, hipEventSynchronize(ctx->flag_events[slot]));
-            if (ctx->h_flags[slot]) break; // loop already left on the device
+            // wait until iteration it - kLag has reported; stop queueing once the loop has ended
+            const int slot = (it - kLag) % kFlagRing, want = it - kLag + 1;
+            volatile int32_t *flag = &ctx->h_flags[slot];
+            int32_t v = *flag;
+            for (long spin = 0; (v >> 1) != want; ++spin) {
+                if (spin > 2000000) { // ~seconds: something is wrong with the stream, find out what
+                    HIP_TRY(ctx, hipStreamSynchronize(s));
+                    v = *flag;
+                    if ((v >> 1) != want) return fail(ctx, ICPMI_ERR_HIP, "device progress word never arrived");
+                    break;
+                }
+                if ((spin & 63) == 63) sched_yield();
+                v = *flag;
+            }
+            if (v & 1) break; // loop already left on the device
         }
-        if ((rc = iteration(0))) return rc;
-        const int slot = it % kFlagRing;
-        HIP_TRY(ctx, hipMemcpyAsync(&ctx->h_flags[slot], &ctx->d_state->done, sizeof(int32_t),
-                                    hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipEventRecord(ctx->flag_events[slot], s));
+        if ((rc = iteration(0, ctx->d_flags + it % kFlagRing, it + 1))) return rc;
     }
     // post-loop evaluation (icp.hpp:235-252): a full pass after exhaustion, a re-statement
     // of the last error after a convergence break
-    if ((rc = iteration(1))) return rc;
+    if ((rc = iteration(1, nullptr, 0))) return rc;
     delete t_loop;
     t_loop = nullptr;
     delete t_total;
@@ -644,13 +657,9 @@ int icpmi_create(const icpmi_options *opt, icpmi_ctx **out)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
     if (hipMalloc((void **)&ctx->d_state, sizeof(IcpState)) != hipSuccess) return bail("hipMalloc state");
     if (hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
-    if (hipHostMalloc((void **)&ctx->h_flags, sizeof(int32_t) * kFlagRing, hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
+    if (hipHostMalloc((void **)&ctx->h_flags, sizeof(int32_t) * kFlagRing, hipHostMallocMapped) != hipSuccess) return bail("hipHostMalloc");
     memset(ctx->h_flags, 0, sizeof(int32_t) * kFlagRing);
-    ctx->flag_events.resize(kFlagRing);
-    for (int i = 0; i < kFlagRing; ++i) {
-        ctx->flag_events[i] = nullptr;
-        if (hipEventCreateWithFlags(&ctx->flag_events[i], hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
-    }
+    if (hipHostGetDevicePointer((void **)&ctx->d_flags, ctx->h_flags, 0) != hipSuccess) return bail("hipHostGetDevicePointer");
     *out = ctx;
     return ICPMI_OK;
 }
@@ -669,8 +678,6 @@ void icpmi_destroy(icpmi_ctx *ctx)
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
-    for (hipEvent_t e : ctx->flag_events)
-        if (e) (void)hipEventDestroy(e);
     for (EventPair &p : ctx->ev_pool) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);

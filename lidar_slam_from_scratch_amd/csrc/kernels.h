@@ -240,13 +240,25 @@ __device__ inline void step_update(IcpState *st, double *history, int final_pass
 }
 
 // single GPU: final sum + step in one launch
+// `progress` (may be null) is one word of host-mapped memory per iteration slot: the device
+// publishes (iteration + 1) * 2 + done there, so the host can stop queueing iterations
+// without any copy or event in the stream.
+__device__ __forceinline__ void publish_progress(int *progress, int ticket, const IcpState *st)
+{
+    if (progress) __hip_atomic_store(progress, ticket * 2 + (st->done ? 1 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(256) void k_finish_step(const double *__restrict__ partials,
                                                      int nblocks, int n_local, IcpState *st,
-                                                     double *history, int final_pass)
+                                                     double *history, int final_pass, int *progress,
+                                                     int ticket)
 {
     if (!st->done) finish_sums(partials, nblocks, n_local, st);
     __syncthreads();
-    if (threadIdx.x == 0) step_update(st, history, final_pass);
+    if (threadIdx.x == 0) {
+        step_update(st, history, final_pass);
+        publish_progress(progress, ticket, st);
+    }
 }
 
 // multi GPU: k_finish -> ncclAllReduce(st->sums, 29) -> k_step
@@ -261,9 +273,12 @@ __global__ __launch_bounds__(256) void k_finish(const double *__restrict__ parti
     finish_sums(partials, nblocks, n_local, st);
 }
 
-__global__ void k_step(IcpState *st, double *history, int final_pass)
+__global__ void k_step(IcpState *st, double *history, int final_pass, int *progress, int ticket)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) step_update(st, history, final_pass);
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        step_update(st, history, final_pass);
+        publish_progress(progress, ticket, st);
+    }
 }
 
 // one-shot solve for icpmi_solve_point_to_plane (icp.hpp:89-144)

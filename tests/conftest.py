@@ -32,7 +32,7 @@ def gpu_ctx(request):
     from lidar_slam_from_scratch_amd import build, capi
     build.build_library()
     search = {"exact_f64": capi.SEARCH_EXACT_F64, "mfma_bf16": capi.SEARCH_MFMA_BF16}[request.param]
-    ctx = capi.Context(device=0, search=search, profile=True)
+    ctx = capi.Context(device=0, search=search, profile=2)
     ctx.engine = request.param
     yield ctx
     ctx.close()
