@@ -665,8 +665,9 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
 // their split's bound are scanned exactly (fp64, reference operation order) and every target
 // with exact distance <= T is collected; the k smallest by (distance, original index) are
 // written closest first -- the order kdtree.hpp:72-76 returns and icp.hpp:41-51 sums in.
-constexpr int kKnnCap = 512;        // candidates per row held in LDS
-constexpr int kKnnMaxSplits = 1024; // per-split bounds cached in LDS (2M targets); beyond: recomputed
+constexpr int kKnnCap = 256;        // candidates per row held in LDS (more: the bound is tightened and the row redone)
+constexpr int kKnnMaxSplits = 256;  // per-split bounds cached in LDS (512k targets); beyond: recomputed
+constexpr int kKnnRegSlots = 32;    // slot minima per lane kept in registers (2048 slots = 131k targets)
 
 // k-th smallest (k = kk, 1-based) of one double per lane; DBL_MAX when fewer than kk are finite
 __device__ __forceinline__ double wave_kth_smallest(double v, int lane, int kk)
@@ -701,10 +702,22 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     const int kk = k < 64 ? k : 64;
     const double kInf = 1.7976931348623157e308;
 
-    // per-lane minimum of the slot minima, with its slot
+    // per-lane minimum of the slot minima, with its slot.  The first kKnnRegSlots values per
+    // lane stay in registers for the flagging pass below (the slot minima are the bulk of this
+    // kernel's HBM traffic: read them once).
+    float sv[kKnnRegSlots];
     float lmin = kBig;
     int lslot = lane < nslots ? lane : 0;
-    for (int e = lane; e < nslots; e += 64) {
+#pragma unroll
+    for (int u = 0; u < kKnnRegSlots; ++u) {
+        const int e = lane + 64 * u;
+        sv[u] = e < nslots ? mine[e] : kBig;
+        if (sv[u] < lmin) {
+            lmin = sv[u];
+            lslot = e;
+        }
+    }
+    for (int e = lane + 64 * kKnnRegSlots; e < nslots; e += 64) {
         const float v = mine[e];
         if (v < lmin) {
             lmin = v;
@@ -779,10 +792,25 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             }
             total = __popcll(m0);
         }
-        for (int e0 = 0; e0 < nslots; e0 += 64) {
+        // flags of the register-resident slots first (static indexing), as a bit mask
+        unsigned regflags = 0u;
+#pragma unroll
+        for (int u = 0; u < kKnnRegSlots; ++u) {
+            const int e = lane + 64 * u;
+            if (e < nslots && e != bslot) {
+                const int sp = e / kCols;
+                const float tauf = sp < kKnnMaxSplits ? tau_sp[wave][sp]
+                                                      : (T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[sp], T, sq));
+                regflags |= sv[u] <= tauf ? (1u << u) : 0u;
+            }
+        }
+#pragma unroll 1
+        for (int e0 = 0, u = 0; e0 < nslots; e0 += 64, ++u) {
             const int e = e0 + lane;
             bool flag = false;
-            if (e < nslots && e != bslot) {
+            if (u < kKnnRegSlots) {
+                flag = (regflags >> u) & 1u;
+            } else if (e < nslots && e != bslot) {
                 const int sp = e / kCols;
                 const float tauf = sp < kKnnMaxSplits ? tau_sp[wave][sp]
                                                       : (T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[sp], T, sq));
