@@ -1,0 +1,92 @@
+"""Frame-to-frame odometry driver: `SlamNode::process_frame` minus ROS
+(slam_viz/src/ros/slam_node.cpp:118-157), the primary caller of the ICP hot path.
+
+    curr = voxel_downsample(load(frame))                      :121-122  (caller supplies clouds)
+    if curr.rows() < min_points: repeat last pose; prev = curr :125-130
+    result = icp_point_to_plane(source=curr, target=prev, cfg) :132-138
+    delta = identity if (!converged || final_error > 1.0)      :139-140
+    new_pose = poses.back() * delta                            :142
+    prev = curr                                                :152
+
+`align` is any callable (source, target, max_iterations, tolerance) -> object with
+.transformation (4x4), .converged, .final_error, .num_iterations -- the HIP library in the
+product, the oracle in the parity tests.
+"""
+import time
+
+import numpy as np
+
+
+class OdometryTrack:
+    def __init__(self):
+        self.poses = [np.eye(4)]          # slam_node.cpp:63-64: pose 0 = identity
+        self.deltas = []
+        self.final_errors = []
+        self.iterations = []
+        self.converged = []
+        self.gated = []                   # True where the identity fallback was taken
+        self.frame_ms = []
+
+    def positions(self):
+        return np.array([p[:3, 3] for p in self.poses])
+
+
+def run_odometry(frames, align, max_iterations=50, tolerance=1e-6, min_points=1000):
+    """frames: iterable of N x 3 fp64 clouds in the sensor frame (already downsampled)."""
+    track = OdometryTrack()
+    prev = None
+    for k, curr in enumerate(frames):
+        curr = np.ascontiguousarray(curr, dtype=np.float64)
+        if k == 0:
+            prev = curr                    # slam_node.cpp:69-72
+            continue
+        t0 = time.perf_counter()
+        if curr.shape[0] < min_points:     # slam_node.cpp:125-130
+            track.poses.append(track.poses[-1].copy())
+            track.deltas.append(np.eye(4))
+            track.final_errors.append(float("nan"))
+            track.iterations.append(0)
+            track.converged.append(False)
+            track.gated.append(True)
+            prev = curr
+            track.frame_ms.append(1e3 * (time.perf_counter() - t0))
+            continue
+        r = align(curr, prev, max_iterations, tolerance)
+        bad = (not r.converged) or r.final_error > 1.0       # slam_node.cpp:139-140
+        delta = np.eye(4) if bad else np.asarray(r.transformation, dtype=np.float64)
+        track.poses.append(track.poses[-1] @ delta)           # slam_node.cpp:142
+        track.deltas.append(delta)
+        track.final_errors.append(r.final_error)
+        track.iterations.append(r.num_iterations)
+        track.converged.append(bool(r.converged))
+        track.gated.append(bool(bad))
+        prev = curr                                           # slam_node.cpp:152
+        track.frame_ms.append(1e3 * (time.perf_counter() - t0))
+    return track
+
+
+def gpu_align(ctx):
+    """Adapter: capi.Context -> the `align` callable above."""
+    from . import capi
+
+    class _R:
+        pass
+
+    def align(source, target, max_iterations, tolerance):
+        cfg = capi.Context.make_config(max_iterations=max_iterations, tolerance=tolerance)
+        res, _hist = ctx.align(source, target, cfg)
+        r = _R()
+        r.transformation = np.array(res.transformation[:]).reshape(4, 4)
+        r.converged = bool(res.converged)
+        r.final_error = res.final_error
+        r.num_iterations = res.num_iterations
+        return r
+
+    return align
+
+
+def absolute_trajectory_error(track, truth_poses):
+    """RMS translation error against ground-truth poses expressed relative to frame 0."""
+    t0_inv = np.linalg.inv(truth_poses[0])
+    err = [np.linalg.norm((t0_inv @ T)[:3, 3] - P[:3, 3]) for T, P in zip(truth_poses, track.poses)]
+    return float(np.sqrt(np.mean(np.square(err))))

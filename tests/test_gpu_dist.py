@@ -22,14 +22,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, npts=3001):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from lidar_slam_from_scratch_amd import capi, dist as icpdist, synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    src, tgt, _ = synth.c1_room_corner(3001)
+    src, tgt, _ = synth.c1_room_corner(npts)
     lo, hi = icpdist.shard_bounds(src.shape[0], world, rank)
     ctx = capi.Context(device=0)
     icpdist.init_callbacks(ctx, dist)
@@ -42,14 +42,16 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_align_on_one_gpu(tmp_path, oracle, gpu_ctx, world):
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,npts", [(2, 3001), (3, 3001), (2, 12001)])
+def test_sharded_align_on_one_gpu(tmp_path, oracle, gpu_ctx, world, npts):
+    """npts = 12001 is past the size where AUTO picks the MFMA engine, so the sharded path
+    also covers the Morton pre-pass, row-sliced MFMA normals and their all-gather."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), npts), nprocs=world, join=True)
     r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(world)]
     for k in range(1, world):
         assert (r[0]["T"] == r[k]["T"]).all() and (r[0]["hist"] == r[k]["hist"]).all()
     from lidar_slam_from_scratch_amd import capi, synth
-    src, tgt, _ = synth.c1_room_corner(3001)
+    src, tgt, _ = synth.c1_room_corner(npts)
     ref = oracle.icp_point_to_plane(src, tgt)
     assert bool(r[0]["conv"]) == ref.converged and int(r[0]["iters"]) == ref.num_iterations
     dt, dr = synth.pose_delta(r[0]["T"], ref.transformation)

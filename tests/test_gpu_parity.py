@@ -262,6 +262,30 @@ def test_host_mirror_api(gpu_ctx, oracle):
     assert (matched == tgt[oidx]).all() and (dist == np.sqrt(od2)).all()
 
 
+# ------------------------------------------------------------------ odometry stream
+def test_odometry_stream_matches_oracle(gpu_ctx, oracle):
+    """process_frame minus ROS (slam_node.cpp:118-157) over a short synthetic drive: same
+    poses, gates and iteration counts as the oracle-driven loop; ATE vs ground truth."""
+    from lidar_slam_from_scratch_amd import odometry
+
+    frames = [synth.lidar_frame(f, beams=32, azimuths=900) for f in range(5)]
+    frames.insert(3, frames[2][:500])          # a too-small frame: min_points guard
+    truth = [synth.lidar_pose(f) for f in (0, 1, 2, 2, 3, 4)]
+
+    def oracle_align(src, tgt, max_it, tol):
+        return oracle.icp_point_to_plane(src, tgt, max_it, tol, 1e-9)
+
+    ref = odometry.run_odometry(frames, oracle_align)
+    got = odometry.run_odometry(frames, odometry.gpu_align(gpu_ctx))
+    assert got.iterations == ref.iterations and got.gated == ref.gated and got.converged == ref.converged
+    assert got.gated[2] and got.iterations[2] == 0              # the small frame repeats the pose
+    for a, b in zip(got.poses, ref.poses):
+        dt, dr = synth.pose_delta(a, b)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+    assert abs(odometry.absolute_trajectory_error(got, truth)
+               - odometry.absolute_trajectory_error(ref, truth)) < 1e-9
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_error_codes(gpu_ctx):
     cfg = capi.Context.make_config()
