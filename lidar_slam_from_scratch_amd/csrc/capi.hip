@@ -509,7 +509,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, ctx->d_state))) return r2;
         {
             StageTimer t(ctx, ST_REDUCE);
-            hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, cur, n, d_tgt, nrm, idx,
+            hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, cur, n, d_tgt, m, nrm, idx,
                                partials, ctx->d_state);
             if (ctx->n_ranks > 1) {
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, partials, rblocks, n,
@@ -794,7 +794,7 @@ int icpmi_solve_point_to_plane(icpmi_ctx *ctx, const double *source_xyz, const d
     {
         StageTimer t(ctx, ST_REDUCE);
         hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, (const double *)ctx->stage_a.p, n,
-                           (const double *)ctx->stage_b.p, (const double *)ctx->stage_c.p,
+                           (const double *)ctx->stage_b.p, n, (const double *)ctx->stage_c.p,
                            (const int *)nullptr, (double *)ctx->partials.p, (const IcpState *)nullptr);
         hipLaunchKernelGGL(k_finish_solve, dim3(1), dim3(256), 0, s, (const double *)ctx->partials.p,
                            rblocks, n, ctx->d_state);

@@ -129,7 +129,7 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 __global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ cur, int n,
-                                                const double *__restrict__ tgt,
+                                                const double *__restrict__ tgt, int m_tgt,
                                                 const double *__restrict__ nrm,
                                                 const int *__restrict__ idx,
                                                 double *__restrict__ partials,
@@ -140,7 +140,10 @@ __global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ cur, 
 #pragma unroll
     for (int e = 0; e < 28; ++e) acc[e] = 0.0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int j = idx ? idx[i] : i;
+        int j = idx ? idx[i] : i;
+        // a query with NaN/Inf coordinates has no nearest neighbour (index -1, like
+        // kdtree.hpp:53); the sums are garbage then anyway, but the gather must stay in bounds
+        j = (unsigned)j < (unsigned)m_tgt ? j : 0;
         const double p0 = cur[3 * i], p1 = cur[3 * i + 1], p2 = cur[3 * i + 2];
         const double q0 = tgt[3 * j], q1 = tgt[3 * j + 1], q2 = tgt[3 * j + 2];
         const double n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];

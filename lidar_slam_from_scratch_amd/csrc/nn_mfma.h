@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
         }
     }
     if (valid && quarter == 0) {
-        idx[i] = bj;
+        idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
         if (d2out) d2out[i] = bd;
     }
     if (counters) {
@@ -679,7 +679,7 @@ __device__ __forceinline__ double wave_kth_smallest(double v, int lane, int kk)
         rank += (o < v || (o == v && L < lane)) ? 1 : 0;
     }
     const unsigned long long who = __ballot(rank == kk - 1);
-    return __shfl(v, __ffsll((long long)who) - 1, 64);
+    return __shfl(v, who ? __ffsll((long long)who) - 1 : 0, 64);
 }
 
 __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ pts, int row0, int nrows,
@@ -731,8 +731,10 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         const float v = __shfl(lmin, L, 64);
         rank += (v < lmin || (v == lmin && L < lane)) ? 1 : 0;
     }
-    const float tS = __shfl(lmin, __ffsll((long long)__ballot(rank == kk - 1)) - 1, 64);
-    const int bslot = __shfl(lslot, __ffsll((long long)__ballot(rank == 0)) - 1, 64);
+    // (a row with NaN coordinates ranks every lane 0: the ballots may be empty -> lane 0)
+    const unsigned long long whoK = __ballot(rank == kk - 1), who0 = __ballot(rank == 0);
+    const float tS = __shfl(lmin, whoK ? __ffsll((long long)whoK) - 1 : 0, 64);
+    const int bslot = __shfl(lslot, who0 ? __ffsll((long long)who0) - 1 : 0, 64);
     double a;
     {
         const SplitFrame &f = frames[lslot / kCols];
@@ -1015,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_normals_from_knn(const double *__restri
     if (cnt >= 3) {
         double cx = 0.0, cy = 0.0, cz = 0.0; // icp.hpp:40-44
         for (int a = 0; a < cnt; ++a) {
-            const int j = nb[a];
+            const int j = (unsigned)nb[a] < (unsigned)m ? nb[a] : i; // rows with NaN coordinates have no list
             cx += pts[3 * j];
             cy += pts[3 * j + 1];
             cz += pts[3 * j + 2];
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_normals_from_knn(const double *__restri
         cz /= kd;
         double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0; // icp.hpp:47-52
         for (int a = 0; a < cnt; ++a) {
-            const int j = nb[a];
+            const int j = (unsigned)nb[a] < (unsigned)m ? nb[a] : i;
             const double dx = pts[3 * j] - cx, dy = pts[3 * j + 1] - cy, dz = pts[3 * j + 2] - cz;
             c00 += dx * dx;
             c01 += dx * dy;
