@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Secondary measurements (BASELINE.json configs[1], [3], [4] stand-ins): not the headline
+bench.  Prints one JSON object."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401
+import numpy as np
+from lidar_slam_from_scratch_amd import capi, synth, odometry
+from oracle import oracle as orc
+
+out = {}
+ctx = capi.Context(device=0, profile=1)
+
+# C2 stand-in: LiDAR-like pair, ~20k points, reference defaults (50 it, tol 1e-6)
+src, tgt, T = synth.c2_lidar_pair()
+cfg = capi.Context.make_config()
+ctx.align(src, tgt, cfg)
+t0 = time.perf_counter(); res, hist = ctx.align(src, tgt, cfg); g = time.perf_counter() - t0
+t0 = time.perf_counter(); ref = orc.icp_point_to_plane(src, tgt); c = time.perf_counter() - t0
+dt, dr = synth.pose_delta(np.array(res.transformation[:]).reshape(4, 4), ref.transformation)
+out["c2_lidar_pair"] = {"n_src": int(src.shape[0]), "n_tgt": int(tgt.shape[0]), "gpu_call_ms": 1e3 * g,
+                        "cpu_call_ms": 1e3 * c, "iterations": res.num_iterations, "pose_dt": dt, "pose_dr": dr,
+                        "iters_equal": res.num_iterations == ref.num_iterations}
+
+# C5 stand-in: 12-frame synthetic drive, frame-to-frame odometry
+frames = [synth.lidar_frame(f) for f in range(12)]
+truth = [synth.lidar_pose(f) for f in range(12)]
+odometry.run_odometry(frames[:3], odometry.gpu_align(ctx))
+t0 = time.perf_counter(); tr = odometry.run_odometry(frames, odometry.gpu_align(ctx)); g = time.perf_counter() - t0
+t0 = time.perf_counter()
+rf = odometry.run_odometry(frames, lambda s, t, mi, tol: orc.icp_point_to_plane(s, t, mi, tol, 1e-9))
+c = time.perf_counter() - t0
+out["c5_odometry_12_frames"] = {"points_per_frame": int(np.mean([f.shape[0] for f in frames])),
+                                "gpu_ms_per_frame": 1e3 * g / 11, "cpu_ms_per_frame": 1e3 * c / 11,
+                                "ate_gpu_m": odometry.absolute_trajectory_error(tr, truth),
+                                "ate_cpu_m": odometry.absolute_trajectory_error(rf, truth),
+                                "iterations_equal": tr.iterations == rf.iterations}
+
+# C4: 1M -> 1M on one GPU, 3 iterations, against the oracle with all host cores
+if "--c4" in sys.argv:
+    src, tgt, T = synth.c4_uniform()
+    cfg = capi.Context.make_config(3, 0.0, 0.0)
+    t0 = time.perf_counter(); res, hist = ctx.align(src, tgt, cfg); g = time.perf_counter() - t0
+    p = ctx.get_profile()
+    nth = os.cpu_count() or 8
+    t0 = time.perf_counter(); ref = orc.icp_point_to_plane(src, tgt, 3, 0.0, 0.0, faithful=False, nthreads=nth); c = time.perf_counter() - t0
+    dt, dr = synth.pose_delta(np.array(res.transformation[:]).reshape(4, 4), ref.transformation)
+    out["c4_1M_3_iterations"] = {"gpu_call_s": g, "cpu_call_s_%d_threads" % nth: c, "pose_dt": dt, "pose_dr": dr,
+                                 "hist_max_abs_diff": float(np.abs(hist - ref.error_history).max()),
+                                 "coarse_ms_per_pass": p["coarse_ms"] / max(p["coarse_launches"], 1)}
+print(json.dumps(out, indent=1))
