@@ -251,8 +251,13 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     return ICPMI_OK;
 }
 
+// when d_nrm/d_partials are given the resolve kernel also does k_reduce's work (one partial
+// row per resolve workgroup: resolve_blocks(n) rows)
+int resolve_blocks(int n) { return (n + 4 * kResolveQ - 1) / (4 * kResolveQ); }
+
 int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx, double *d_d2,
-                   const IcpState *st)
+                   const IcpState *st, const double *d_tgt = nullptr, const double *d_nrm = nullptr,
+                   double *d_partials = nullptr)
 {
     const int splits = ctx->nn_splits;
     int rc;
@@ -275,9 +280,9 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
         }
     }
 #undef ICPMI_COARSE
-    hipLaunchKernelGGL(k_nn_resolve, dim3((n + 4 * kResolveQ - 1) / (4 * kResolveQ)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(k_nn_resolve, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream,
                        d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits,
-                       frames, d_idx, d_d2, counters, st);
+                       frames, d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, st);
     ctx->prof.nn_pairs += (double)n * (double)m;
     HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;
@@ -456,14 +461,11 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     if ((rc = reserve(ctx, ctx->cur, sizeof(double) * 3 * (size_t)n))) return rc;
     if ((rc = reserve(ctx, ctx->nrm, sizeof(double) * 3 * (size_t)m))) return rc;
     if ((rc = reserve(ctx, ctx->idx, sizeof(int) * (size_t)n))) return rc;
-    const int rblocks = reduce_blocks(ctx, n);
-    if ((rc = reserve(ctx, ctx->partials, sizeof(double) * kSumsStride * (size_t)rblocks))) return rc;
     if ((rc = reserve(ctx, ctx->history, sizeof(double) * (size_t)(max_hist + 1)))) return rc;
 
     double *cur = (double *)ctx->cur.p;
     double *nrm = (double *)ctx->nrm.p;
     int *idx = (int *)ctx->idx.p;
-    double *partials = (double *)ctx->partials.p;
     double *hist = (double *)ctx->history.p;
 
     StageTimer *t_total = new StageTimer(ctx, ST_TOTAL);
@@ -480,6 +482,11 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state, hs, sizeof(IcpState), hipMemcpyHostToDevice, s));
 
     if ((rc = prepare_nn(ctx, d_tgt, m, n))) return rc;
+    // with the MFMA engine the resolve kernel also forms the normal-equation partial sums
+    const bool fused = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16;
+    const int rblocks = fused ? resolve_blocks(n) : reduce_blocks(ctx, n);
+    if ((rc = reserve(ctx, ctx->partials, sizeof(double) * kSumsStride * (size_t)rblocks))) return rc;
+    double *partials = (double *)ctx->partials.p;
 
     // normals of the target (icp.hpp:169-171).  With several ranks each computes a slice of
     // rows against the full target and the slices are all-gathered.
@@ -506,11 +513,16 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
 
     auto iteration = [&](int final_pass, int *progress, int ticket) -> int {
         int r2;
-        if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, ctx->d_state))) return r2;
+        if (fused) {
+            if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, ctx->d_state, d_tgt, nrm, partials))) return r2;
+        } else {
+            if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, ctx->d_state))) return r2;
+        }
         {
             StageTimer t(ctx, ST_REDUCE);
-            hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, cur, n, d_tgt, m, nrm, idx,
-                               partials, ctx->d_state);
+            if (!fused)
+                hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, cur, n, d_tgt, m, nrm, idx, partials,
+                                   ctx->d_state);
             if (ctx->n_ranks > 1) {
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, partials, rblocks, n,
                                    ctx->d_state);

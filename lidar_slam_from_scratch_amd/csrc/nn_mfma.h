@@ -524,14 +524,16 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
                                                     const SplitFrame *__restrict__ frames,
                                                     int *__restrict__ idx, double *__restrict__ d2out,
                                                     unsigned long long *__restrict__ counters,
+                                                    const double *__restrict__ tgt_orig,
+                                                    const double *__restrict__ nrm,
+                                                    double *__restrict__ partials,
                                                     const IcpState *__restrict__ st)
 {
     if (st && st->done) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ql = lane & 15, quarter = lane >> 4;
-    const int qbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kResolveQ;
-    if (qbase >= n) return; // wave-uniform
-    const int i = qbase + ql;
+    const int qbase = (blockIdx.x * 4 + wave) * kResolveQ;
+    const int i = qbase + ql; // waves past the end run on a clamped query and write nothing
     const bool valid = i < n;
     const int ic = valid ? i : n - 1;
     const double px = qry[3 * ic], py = qry[3 * ic + 1], pz = qry[3 * ic + 2];
@@ -647,6 +649,49 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
         if (lane == 0 && (es | ef)) {
             atomicAdd(&counters[0], (unsigned long long)es);
             atomicAdd(&counters[1], (unsigned long long)ef);
+        }
+    }
+    // fused residual + normal equations (what k_reduce does, icp.hpp:99-120,198-206): the 16
+    // owners of a wave form their J row and b, the 28 sums go wave -> LDS -> one partial row
+    // per workgroup, summed later in a fixed order by k_finish_step
+    if (partials) {
+        double acc[28];
+#pragma unroll
+        for (int e = 0; e < 28; ++e) acc[e] = 0.0;
+        if (valid && quarter == 0) {
+            const int j = (unsigned)bj < (unsigned)m ? bj : 0;
+            const double q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
+            const double n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
+            double J[6];
+            J[0] = py * n2 - pz * n1; // p x n, icp.hpp:105
+            J[1] = pz * n0 - px * n2;
+            J[2] = px * n1 - py * n0;
+            J[3] = n0;
+            J[4] = n1;
+            J[5] = n2;
+            const double e0 = q0 - px, e1 = q1 - py, e2 = q2 - pz;
+            const double b = (e0 * n0 + e1 * n1) + e2 * n2; // icp.hpp:116
+            int o = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) acc[o++] = J[r] * J[c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[21 + r] = J[r] * b;
+            acc[27] = b * b;
+        }
+        __shared__ double red[4][28];
+#pragma unroll
+        for (int e = 0; e < 28; ++e) {
+            double v = acc[e];
+#pragma unroll
+            for (int x = 1; x < 16; x <<= 1) v += __shfl_xor(v, x, 64); // only lanes 0..15 hold data
+            if (lane == 0) red[wave][e] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 28) {
+            const int e = threadIdx.x;
+            partials[(size_t)blockIdx.x * kSumsStride + e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
         }
     }
 }
