@@ -179,16 +179,29 @@ __global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ cur, 
     }
 }
 
-// sum the per-block partial rows in a fixed order -> st->sums[0..27]; sums[28] = count
+// sum the per-block partial rows in a fixed order -> st->sums[0..27]; sums[28] = count.
+// 256 threads = 8 row groups x 32 columns: every load instruction reads whole 256-byte rows,
+// thread (g, e) adds rows g, g+8, ... of column e, then the 8 groups are added in order.
+// Must be called by the whole workgroup (it synchronises).
 __device__ inline void finish_sums(const double *__restrict__ partials, int nblocks, int n_local,
                                    IcpState *st)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6; // 256 threads
-    for (int e = wave; e < 28; e += 4) {
-        double s = 0.0;
-        for (int b = lane; b < nblocks; b += kWave) s += partials[(size_t)b * kSumsStride + e];
-        s = wave_sum(s);
-        if (lane == 0) st->sums[e] = s;
+    __shared__ double fs[8][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double s0 = 0.0, s1 = 0.0;
+    int b = g;
+    for (; b + 8 < nblocks; b += 16) { // two independent chains: rows b and b+8
+        s0 += partials[(size_t)b * kSumsStride + e];
+        s1 += partials[(size_t)(b + 8) * kSumsStride + e];
+    }
+    if (b < nblocks) s0 += partials[(size_t)b * kSumsStride + e];
+    fs[g][e] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.x < 28) {
+        double s = fs[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s += fs[k][e];
+        st->sums[e] = s;
     }
     if (threadIdx.x == 0) st->sums[28] = (double)n_local;
 }
