@@ -524,12 +524,12 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                 hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, cur, n, d_tgt, m, nrm, idx, partials,
                                    ctx->d_state);
             if (ctx->n_ranks > 1) {
-                hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, partials, rblocks, n,
+                hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
                                    ctx->d_state);
                 if ((r2 = exchange_allreduce(ctx, ctx->d_state->sums, kNumSums))) return r2;
                 hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, ctx->d_state, hist, final_pass, progress, ticket);
             } else {
-                hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(256), 0, s, partials, rblocks, n,
+                hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
                                    ctx->d_state, hist, final_pass, progress, ticket);
             }
         }
@@ -808,7 +808,7 @@ int icpmi_solve_point_to_plane(icpmi_ctx *ctx, const double *source_xyz, const d
         hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, (const double *)ctx->stage_a.p, n,
                            (const double *)ctx->stage_b.p, n, (const double *)ctx->stage_c.p,
                            (const int *)nullptr, (double *)ctx->partials.p, (const IcpState *)nullptr);
-        hipLaunchKernelGGL(k_finish_solve, dim3(1), dim3(256), 0, s, (const double *)ctx->partials.p,
+        hipLaunchKernelGGL(k_finish_solve, dim3(1), dim3(kFinishThreads), 0, s, (const double *)ctx->partials.p,
                            rblocks, n, ctx->d_state);
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));

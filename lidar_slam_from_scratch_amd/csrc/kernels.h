@@ -180,27 +180,36 @@ __global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ cur, 
 }
 
 // sum the per-block partial rows in a fixed order -> st->sums[0..27]; sums[28] = count.
-// 256 threads = 8 row groups x 32 columns: every load instruction reads whole 256-byte rows,
-// thread (g, e) adds rows g, g+8, ... of column e, then the 8 groups are added in order.
-// Must be called by the whole workgroup (it synchronises).
+// kFinishThreads threads = G row groups x 32 columns: every load instruction reads whole
+// 256-byte rows, thread (g, e) adds rows g, g+G, ... of column e with four loads in flight,
+// then the G groups are added in order.  Must be called by the whole workgroup.
+constexpr int kFinishThreads = 1024;
+constexpr int kFinishGroups = kFinishThreads / 32;
+
 __device__ inline void finish_sums(const double *__restrict__ partials, int nblocks, int n_local,
                                    IcpState *st)
 {
-    __shared__ double fs[8][32];
+    __shared__ double fs[kFinishGroups][32];
+    constexpr int G = kFinishGroups;
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
-    double s0 = 0.0, s1 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int b = g;
-    for (; b + 8 < nblocks; b += 16) { // two independent chains: rows b and b+8
-        s0 += partials[(size_t)b * kSumsStride + e];
-        s1 += partials[(size_t)(b + 8) * kSumsStride + e];
+    for (; b + 3 * G < nblocks; b += 4 * G) {
+        const double v0 = partials[(size_t)b * kSumsStride + e];
+        const double v1 = partials[(size_t)(b + G) * kSumsStride + e];
+        const double v2 = partials[(size_t)(b + 2 * G) * kSumsStride + e];
+        const double v3 = partials[(size_t)(b + 3 * G) * kSumsStride + e];
+        s0 += v0;
+        s1 += v1;
+        s2 += v2;
+        s3 += v3;
     }
-    if (b < nblocks) s0 += partials[(size_t)b * kSumsStride + e];
-    fs[g][e] = s0 + s1;
+    for (; b < nblocks; b += G) s0 += partials[(size_t)b * kSumsStride + e];
+    fs[g][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (threadIdx.x < 28) {
         double s = fs[0][e];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) s += fs[k][e];
+        for (int k = 1; k < G; ++k) s += fs[k][e];
         st->sums[e] = s;
     }
     if (threadIdx.x == 0) st->sums[28] = (double)n_local;
@@ -264,7 +273,7 @@ __device__ __forceinline__ void publish_progress(int *progress, int ticket, cons
     if (progress) __hip_atomic_store(progress, ticket * 2 + (st->done ? 1 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(256) void k_finish_step(const double *__restrict__ partials,
+__global__ __launch_bounds__(kFinishThreads) void k_finish_step(const double *__restrict__ partials,
                                                      int nblocks, int n_local, IcpState *st,
                                                      double *history, int final_pass, int *progress,
                                                      int ticket)
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(256) void k_finish_step(const double *__restrict__ 
 }
 
 // multi GPU: k_finish -> ncclAllReduce(st->sums, 29) -> k_step
-__global__ __launch_bounds__(256) void k_finish(const double *__restrict__ partials, int nblocks,
+__global__ __launch_bounds__(kFinishThreads) void k_finish(const double *__restrict__ partials, int nblocks,
                                                 int n_local, IcpState *st)
 {
     if (st->done) {
@@ -298,7 +307,7 @@ __global__ void k_step(IcpState *st, double *history, int final_pass, int *progr
 }
 
 // one-shot solve for icpmi_solve_point_to_plane (icp.hpp:89-144)
-__global__ __launch_bounds__(256) void k_finish_solve(const double *__restrict__ partials,
+__global__ __launch_bounds__(kFinishThreads) void k_finish_solve(const double *__restrict__ partials,
                                                       int nblocks, int n_local, IcpState *st)
 {
     finish_sums(partials, nblocks, n_local, st);
