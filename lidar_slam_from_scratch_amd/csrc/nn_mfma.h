@@ -516,7 +516,6 @@ __device__ __forceinline__ void scan_range(const double *__restrict__ sorted,
 // of the slot: three coalesced streams), so 4 slots are in flight per wave and ~6 waves per
 // SIMD hide the latency.
 constexpr int kResolveQ = 16;
-constexpr int kResolveReg = 16; // coarse entries per lane kept in registers
 
 __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ qry, int n,
                                                     const double *__restrict__ sorted,
@@ -539,22 +538,10 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
     const int ic = valid ? i : n - 1;
     const double px = qry[3 * ic], py = qry[3 * ic + 1], pz = qry[3 * ic + 2];
 
-    // phase 1: smallest coarse value over the splits (each quarter takes every 4th split).
-    // The first kResolveReg entries per quarter (64 splits = 131k targets) stay in registers
-    // for the certificate pass: the coarse array is then read once per pass.
-    float2 cv[kResolveReg];
+    // phase 1: smallest coarse value over the splits (each quarter takes every 4th split)
     float best = kBig;
     int bs = 0;
-#pragma unroll
-    for (int u = 0; u < kResolveReg; ++u) {
-        const int s = quarter + 4 * u;
-        cv[u] = s < splits ? coarse[(size_t)s * n + ic] : make_float2(kBig, kBig);
-        if (cv[u].x < best) {
-            best = cv[u].x;
-            bs = s;
-        }
-    }
-    for (int s = quarter + 4 * kResolveReg; s < splits; s += 4) {
+    for (int s = quarter; s < splits; s += 4) {
         const float v = coarse[(size_t)s * n + ic].x;
         if (v < best) {
             best = v;
@@ -615,30 +602,11 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
     // phase 3: certificate, split by split (tau depends on the split's frame)
     const double sq = sqrt(bd);
     unsigned extra_slots = 0, extra_splits = 0;
-    // flags of the register-resident splits first (static indexing), packed two bits each
-    unsigned regflags = 0u;
-#pragma unroll
-    for (int u = 0; u < kResolveReg; ++u) {
-        const int s = quarter + 4 * u;
-        if (s < splits && valid) {
-            const float tauf = split_tau(px, py, pz, frames[s], bd, sq);
-            const bool whole = cv[u].y <= tauf;
-            const bool slot = !whole && s != bs && cv[u].x <= tauf;
-            regflags |= (whole ? 2u : (slot ? 1u : 0u)) << (2 * u);
-        }
-    }
-#pragma unroll 1
-    for (int s0 = 0, u = 0; s0 < splits; s0 += 4, ++u) {
+    for (int s0 = 0; s0 < splits; s0 += 4) {
         const int s = s0 + quarter;
         bool whole = false, slot = false;
         float2 v = make_float2(kBig, kBig);
-        if (u < kResolveReg) {
-            whole = (regflags >> (2 * u)) & 2u;
-            slot = (regflags >> (2 * u)) & 1u;
-            if (__ballot(whole || slot)) { // rare: fetch the tag again instead of indexing cv[]
-                if (s < splits) v = coarse[(size_t)s * n + ic];
-            }
-        } else if (s < splits && valid) {
+        if (s < splits && valid) {
             v = coarse[(size_t)s * n + ic];
             const float tauf = split_tau(px, py, pz, frames[s], bd, sq);
             whole = v.y <= tauf;                       // a second column is inside the bound
