@@ -490,7 +490,8 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
 
     // normals of the target (icp.hpp:169-171).  With several ranks each computes a slice of
     // rows against the full target and the slices are all-gathered.
-    if (ctx->n_ranks > 1) {
+    const bool sharded = ctx->comm != nullptr || ctx->cb_allreduce != nullptr; // exchanges on, even for 1 rank
+    if (sharded) {
         const int per = (m + ctx->n_ranks - 1) / ctx->n_ranks;
         if ((rc = reserve(ctx, ctx->stage_a, sizeof(double) * 3 * (size_t)per * ctx->n_ranks))) return rc;
         double *gathered = (double *)ctx->stage_a.p;
@@ -523,7 +524,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
             if (!fused)
                 hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, cur, n, d_tgt, m, nrm, idx, partials,
                                    ctx->d_state);
-            if (ctx->n_ranks > 1) {
+            if (sharded) {
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
                                    ctx->d_state);
                 if ((r2 = exchange_allreduce(ctx, ctx->d_state->sums, kNumSums))) return r2;
@@ -866,11 +867,12 @@ int icpmi_comm_init(icpmi_ctx *ctx, int32_t n_ranks, int32_t rank, const void *i
     if ((rc = check_common(ctx))) return rc;
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ctx, ICPMI_ERR_ARG, "bad rank %d of %d", rank, n_ranks);
     if (ctx->comm) return fail(ctx, ICPMI_ERR_ARG, "communicator already initialised");
-    if (n_ranks == 1) {
+    if (n_ranks == 1 && !id) { // no communicator wanted
         ctx->n_ranks = 1;
         ctx->rank = 0;
         return ICPMI_OK;
     }
+    // (a 1-rank communicator is allowed: it runs the full sharded path, exchanges included)
     if (!id) return fail(ctx, ICPMI_ERR_NULL, "id is NULL");
     if ((rc = load_rccl(ctx))) return rc;
     ncclUniqueId uid;

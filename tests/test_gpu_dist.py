@@ -60,3 +60,25 @@ def test_sharded_align_on_one_gpu(tmp_path, oracle, gpu_ctx, world, npts):
     single, shist = gpu_ctx.align(src, tgt, capi.Context.make_config())
     assert single.num_iterations == int(r[0]["iters"])
     np.testing.assert_allclose(np.array(single.transformation[:]).reshape(4, 4), r[0]["T"], atol=1e-12)
+
+
+def test_rccl_single_rank_communicator(oracle):
+    """The RCCL plumbing on real hardware (dlopen, unique id, ncclCommInitRank, in-place
+    all-gather of the normals, 29-double all-reduce on the library's stream) with a 1-rank
+    communicator: the sharded code path must reproduce the plain single-GPU result."""
+    from lidar_slam_from_scratch_amd import capi, synth
+    src, tgt, _ = synth.c3_uniform(12000, seed=41, perm_seed=42)
+    cfg = capi.Context.make_config(6, 0.0, 0.0)
+    plain = capi.Context(device=0)
+    r0, h0 = plain.align(src, tgt, cfg)
+    plain.close()
+    ctx = capi.Context(device=0)
+    ctx.comm_init(1, 0, ctx.comm_unique_id())
+    r1, h1 = ctx.align(src, tgt, cfg)
+    ctx.comm_finalize()
+    r2, h2 = ctx.align(src, tgt, cfg)       # and back to the plain path
+    ctx.close()
+    assert r1.num_iterations == r0.num_iterations == r2.num_iterations
+    np.testing.assert_allclose(h1, h0, rtol=0, atol=1e-12)
+    assert (h2 == h0).all()
+    np.testing.assert_allclose(np.array(r1.transformation[:]), np.array(r0.transformation[:]), atol=1e-12)
