@@ -72,8 +72,6 @@ struct icpmi_ctx {
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
     int nn_splits = 0;
-    int coarse_qt = kCoarseQT;                // 32-query tiles per wave of the coarse kernel (2 or 4)
-    int coarse_var = kCoarseVar;              // scheduling variant of the coarse kernel
     int nn_ms = 0;                            // component stride of the SoA sorted target
     IcpState *d_state = nullptr;
     IcpState *h_state = nullptr;   // pinned
@@ -266,20 +264,12 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     const unsigned *perm = (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m;
     unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);
     StageTimer t(ctx, ST_NN);
-#define ICPMI_COARSE(QT, VAR)                                                                              \
-    hipLaunchKernelGGL((k_nn_coarse<0, QT, kCoarseWaves, VAR>), dim3((n + kTile * QT * kCoarseWaves - 1) / (kTile * QT * kCoarseWaves), splits), \
-                       dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,      \
-                       (float2 *)ctx->coarse.p, (float *)nullptr, st)
     {
         StageTimer tc(ctx, ST_COARSE); // the dominant kernel alone (matches rocprofv3's per-kernel average)
-        switch (ctx->coarse_qt * 2 + (ctx->coarse_var & 1)) {
-        case 4 * 2 + 0: ICPMI_COARSE(4, 0); break;
-        case 4 * 2 + 1: ICPMI_COARSE(4, 1); break;
-        case 2 * 2 + 1: ICPMI_COARSE(2, 1); break;
-        default: ICPMI_COARSE(2, 0); break;
-        }
+        hipLaunchKernelGGL((k_nn_coarse<0, kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
+                           dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,
+                           (float2 *)ctx->coarse.p, (float *)nullptr, st);
     }
-#undef ICPMI_COARSE
     hipLaunchKernelGGL(k_nn_resolve, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream,
                        d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits,
                        frames, d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, st);
@@ -348,7 +338,7 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
         const unsigned *perm = (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m;
         for (long c0 = row0; c0 < row1; c0 += chunk) {
             const int nq = (int)std::min<long>(chunk, row1 - c0);
-            hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves, kCoarseVar>), dim3((nq + kCoarseQueries - 1) / kCoarseQueries, splits),
+            hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves>), dim3((nq + kCoarseQueries - 1) / kCoarseQueries, splits),
                                dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
                                frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
             hipLaunchKernelGGL(k_knn_resolve, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq,
@@ -658,8 +648,6 @@ int icpmi_create(const icpmi_options *opt, icpmi_ctx **out)
     icpmi_ctx *ctx = new icpmi_ctx();
     ctx->opt = o;
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *e = getenv("ICPMI_COARSE_QT")) ctx->coarse_qt = atoi(e) == 4 ? 4 : 2; // tuning knobs
-    if (const char *e = getenv("ICPMI_COARSE_VAR")) ctx->coarse_var = atoi(e) & 3;
     memset(&ctx->prof, 0, sizeof(ctx->prof));
     auto bail = [&](const char *what) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(hipGetLastError());

@@ -56,9 +56,8 @@ constexpr int kSplitTiles = 64;                   // target tiles per split
 constexpr int kSplitTargets = kSplitTiles * kTile;// 2048
 constexpr int kSlotTargets = kSplitTiles;         // 64 targets per (split, column) slot
 constexpr int kChunkTiles = 32;                   // tiles staged in LDS at a time (32 KiB)
-constexpr int kCoarseQT = 2;                      // 32-query tiles per wave (2 or 4)
+constexpr int kCoarseQT = 2;                      // 32-query tiles per wave
 constexpr int kCoarseWaves = 8;                   // waves per workgroup
-constexpr int kCoarseVar = 0;                     // default scheduling variant (see k_nn_coarse)
 constexpr int kCoarseThreads = 64 * kCoarseWaves;
 constexpr int kCoarseQueries = kTile * kCoarseQT * kCoarseWaves; // queries per workgroup
 constexpr float kBig = 3.0e38f;
@@ -299,9 +298,10 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
 
 // MODE 0: 1-NN epilogue -> coarse[split][n] = (tagged min, second min over the 32 columns)
 // MODE 1: k-NN epilogue  -> slotmin[query][split*32 + column], every column minimum kept
-// QT = 32-query tiles per wave (2 or 4); WAVES = waves per workgroup; VAR bit 0: the min3
-// of a tile is issued one tile behind its MFMAs (software pipeline).
-template <int MODE, int QT, int WAVES, int VAR>
+// QT = 32-query tiles per wave (even); WAVES = waves per workgroup.  (Tried and dropped, see
+// scripts/micro/README.md: issuing a tile's min3 one tile behind its MFMAs, keeping the next B chunk
+// in flight in registers, QT = 4: none beat this form, all cost occupancy.)
+template <int MODE, int QT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     const double *__restrict__ qry, int n, const uint4 *__restrict__ Bpack,
     const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/,
@@ -312,7 +312,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     constexpr int CHUNK16 = kChunkTiles * 64;  // uint4 per staged chunk (32 KiB)
     constexpr int EPI16 = 32 * 36 / 4;         // uint4 per wave for the epilogue transpose
     constexpr int SCRATCH16 = WAVES * EPI16 > CHUNK16 ? WAVES * EPI16 : CHUNK16;
-    constexpr bool PIPE = VAR & 1;
     if (st && st->done) return;
     __shared__ uint4 lds[SCRATCH16];
     const int s = blockIdx.y;
@@ -363,9 +362,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     f32x16 zero;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-    f32x16 pa, pb; // PIPE: results whose min3 is still pending
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pa[r] = pb[r] = kBig;
 
     // B operands: 2 chunks of 32 tiles through one 32 KiB LDS buffer
     const uint4 *src = Bpack + (size_t)s * (kSplitTiles * 64);
@@ -384,26 +380,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
             for (int t = 0; t < QT; ++t) {
                 const f32x16 da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[t], b0, zero, 0, 0, 0);
                 const f32x16 db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[t], b1, zero, 0, 0, 0);
-                if (PIPE) {
-                    const int tp = (t + QT - 1) % QT;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m[tp][r] = min3f(m[tp][r], pa[r], pb[r]);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                    pa = da;
-                    pb = db;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) m[t][r] = min3f(m[t][r], da[r], db[r]);
-                }
+                for (int r = 0; r < 16; ++r) m[t][r] = min3f(m[t][r], da[r], db[r]);
             }
         }
-    }
-    if (PIPE) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m[QT - 1][r] = min3f(m[QT - 1][r], pa[r], pb[r]);
     }
 
     // epilogue.  Transpose through LDS, one 32-query tile at a time (row stride 36 floats:
