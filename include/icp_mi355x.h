@@ -130,6 +130,19 @@ int icpmi_solve_point_to_plane(icpmi_ctx *ctx, const double *source_xyz,
 int icpmi_transform_points(icpmi_ctx *ctx, const double transform[16], const double *in_xyz,
                            int64_t n, double *out_xyz);
 
+/* Replaces voxel_downsample(points, voxel_size) (slam_viz/src/core/file_utils.cpp:148-196), the
+ * step slam_node.cpp:122 runs before every registration: centroid of the points of each
+ * occupied voxel, key = floor(coord / voxel_size), points summed in input order.  Voxels come
+ * out sorted by key (the reference's order is std::unordered_map iteration order, i.e.
+ * implementation-defined).  voxel_size <= 0 copies the input (file_utils.cpp:152).  out_cap
+ * is in rows; n rows always suffice.  The grid may span at most 2^21 cells per axis. */
+int icpmi_voxel_downsample(icpmi_ctx *ctx, const double *points_xyz, int64_t n, double voxel_size,
+                           double *out_xyz, int64_t out_cap, int64_t *n_out);
+/* Same on device pointers (the result can feed icpmi_align_device without leaving HBM). */
+int icpmi_voxel_downsample_device(icpmi_ctx *ctx, const double *d_points_xyz, int64_t n,
+                                  double voxel_size, double *d_out_xyz, int64_t out_cap,
+                                  int64_t *n_out);
+
 /* Multi-GPU (new; the reference has no distributed path).  One process per GPU.  Rank 0
  * obtains an id, the host distributes it (e.g. torch.distributed broadcast), every rank
  * calls icpmi_comm_init.  Afterwards icpmi_align* treats `source` as this rank's shard

@@ -21,7 +21,7 @@ EXPORTS = [
     "icpmi_destroy", "icpmi_last_error", "icpmi_align", "icpmi_align_device",
     "icpmi_nearest_batch", "icpmi_estimate_normals", "icpmi_solve_point_to_plane",
     "icpmi_transform_points", "icpmi_comm_unique_id", "icpmi_comm_init", "icpmi_comm_finalize",
-    "icpmi_comm_init_callbacks",
+    "icpmi_comm_init_callbacks", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
     "icpmi_reset_profile", "icpmi_get_profile",
 ]
 
@@ -96,6 +96,9 @@ def load_library(path=None):
     L.icpmi_estimate_normals.argtypes = [vp, dp, C.c_int64, C.c_int32, dp]
     L.icpmi_solve_point_to_plane.argtypes = [vp, dp, dp, dp, C.c_int64, dp]
     L.icpmi_transform_points.argtypes = [vp, dp, dp, C.c_int64, dp]
+    i64p = C.POINTER(C.c_int64)
+    L.icpmi_voxel_downsample.argtypes = [vp, dp, C.c_int64, C.c_double, dp, C.c_int64, i64p]
+    L.icpmi_voxel_downsample_device.argtypes = [vp, vp, C.c_int64, C.c_double, vp, C.c_int64, i64p]
     L.icpmi_comm_unique_id.argtypes = [vp, vp]
     L.icpmi_comm_init.argtypes = [vp, C.c_int32, C.c_int32, vp]
     L.icpmi_comm_finalize.argtypes = [vp]
@@ -202,6 +205,21 @@ class Context:
         out = np.empty_like(pts)
         self._check(self._lib.icpmi_transform_points(self._h, _dp(Tm), _dp(pts), pts.shape[0], _dp(out)))
         return out
+
+    def voxel_downsample(self, points, voxel_size):
+        """file_utils.cpp:148-196 on the GPU; voxels sorted by key."""
+        pts = _f64(points)
+        out = np.empty_like(pts)
+        n_out = C.c_int64(0)
+        self._check(self._lib.icpmi_voxel_downsample(self._h, _dp(pts), pts.shape[0], float(voxel_size),
+                                                     _dp(out), pts.shape[0], C.byref(n_out)))
+        return out[:n_out.value].copy()
+
+    def voxel_downsample_device(self, src_ptr, n, voxel_size, out_ptr, out_cap):
+        n_out = C.c_int64(0)
+        self._check(self._lib.icpmi_voxel_downsample_device(self._h, C.c_void_p(src_ptr), n, float(voxel_size),
+                                                            C.c_void_p(out_ptr), out_cap, C.byref(n_out)))
+        return n_out.value
 
     # multi-GPU
     def comm_unique_id(self):

@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <sched.h>
@@ -24,12 +25,21 @@
 #include "../../include/icp_mi355x.h"
 #include "kernels.h"
 #include "nn_mfma.h"
+#include "voxel.h"
 
 using namespace icpmi;
 
 namespace icpmi {
 hipError_t sort_pairs_u32(void *temp, size_t *temp_bytes, const unsigned *keys_in, unsigned *keys_out,
                           const unsigned *vals_in, unsigned *vals_out, unsigned n, hipStream_t stream);
+hipError_t sort_pairs_u64(void *temp, size_t *temp_bytes, const unsigned long long *keys_in,
+                          unsigned long long *keys_out, const unsigned *vals_in, unsigned *vals_out,
+                          unsigned n, hipStream_t stream);
+hipError_t run_lengths_u64(void *temp, size_t *temp_bytes, const unsigned long long *keys, unsigned n,
+                           unsigned long long *unique_out, unsigned *counts_out, unsigned *runs_out,
+                           hipStream_t stream);
+hipError_t exclusive_sum_u32(void *temp, size_t *temp_bytes, const unsigned *in, unsigned *out, unsigned n,
+                             hipStream_t stream);
 }
 
 namespace {
@@ -68,6 +78,7 @@ struct icpmi_ctx {
 
     DevBuf cur, nrm, idx, part_d2, part_idx, partials, history, stage_a, stage_b, stage_c, d2out;
     DevBuf knn_idx, slotmin, fb_list;         // k-NN lists, slot minima, rows for the exact fallback
+    DevBuf vox_keys, vox_vals, vox_out;             // voxel filter: 64-bit keys (in/out/unique), values + run data, result
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
@@ -581,6 +592,66 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     return ICPMI_OK;
 }
 
+// voxel filter on device memory -> d_out (n_out rows); see voxel.h
+int voxel_downsample_device(icpmi_ctx *ctx, const double *d_pts, int n, double voxel, double *d_out,
+                            int64_t out_cap, int64_t *n_out)
+{
+    hipStream_t s = ctx->stream;
+    int rc;
+    if (!(voxel > 0.0)) { // file_utils.cpp:152: returns the input unchanged
+        if (out_cap < n) return fail(ctx, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %d", (long long)out_cap, n);
+        HIP_TRY(ctx, hipMemcpyAsync(d_out, d_pts, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        *n_out = n;
+        return ICPMI_OK;
+    }
+    // key origin from the bounding box
+    const int bblocks = std::max(1, std::min(256, (n + 255) / 256));
+    if ((rc = reserve(ctx, ctx->bbox_part, sizeof(double) * 6 * (size_t)bblocks))) return rc;
+    if ((rc = reserve(ctx, ctx->nn_misc, 256))) return rc;
+    NnFrame *frame = (NnFrame *)ctx->nn_misc.p;
+    hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_pts, n, (double *)ctx->bbox_part.p);
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, frame);
+    NnFrame hf;
+    HIP_TRY(ctx, hipMemcpyAsync(&hf, frame, sizeof(NnFrame), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    long long k0[3];
+    for (int a = 0; a < 3; ++a) {
+        const double lo = floor(hf.lo[a] / voxel), hi = floor(hf.hi[a] / voxel);
+        if (!(lo == lo) || !(hi == hi) || hi - lo >= 2097152.0 || fabs(lo) > 4.0e18 || fabs(hi) > 4.0e18)
+            return fail(ctx, ICPMI_ERR_ARG, "voxel grid spans more than 2^21 cells on axis %d (or non-finite points)", a);
+        k0[a] = (long long)lo;
+    }
+    // keys_in | keys_out | unique ; vals_in | order | counts | offsets | runs
+    const size_t un = (size_t)n;
+    if ((rc = reserve(ctx, ctx->vox_keys, sizeof(unsigned long long) * 3 * un))) return rc;
+    if ((rc = reserve(ctx, ctx->vox_vals, sizeof(unsigned) * (4 * un + 16)))) return rc;
+    unsigned long long *keys_in = (unsigned long long *)ctx->vox_keys.p, *keys_out = keys_in + un, *uniq = keys_in + 2 * un;
+    unsigned *vals_in = (unsigned *)ctx->vox_vals.p, *order = vals_in + un, *counts = vals_in + 2 * un,
+             *offsets = vals_in + 3 * un, *runs_d = vals_in + 4 * un;
+    size_t b1 = 0, b2 = 0, b3 = 0;
+    HIP_TRY(ctx, sort_pairs_u64(nullptr, &b1, keys_in, keys_out, vals_in, order, (unsigned)n, s));
+    HIP_TRY(ctx, run_lengths_u64(nullptr, &b2, keys_out, (unsigned)n, uniq, counts, runs_d, s));
+    HIP_TRY(ctx, exclusive_sum_u32(nullptr, &b3, counts, offsets, (unsigned)n, s));
+    size_t tmp_bytes = std::max(b1, std::max(b2, b3));
+    if ((rc = reserve(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
+    hipLaunchKernelGGL(k_voxel_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_pts, n, voxel, k0[0], k0[1], k0[2],
+                       keys_in, vals_in);
+    HIP_TRY(ctx, sort_pairs_u64(ctx->sort_tmp.p, &b1, keys_in, keys_out, vals_in, order, (unsigned)n, s));
+    HIP_TRY(ctx, run_lengths_u64(ctx->sort_tmp.p, &b2, keys_out, (unsigned)n, uniq, counts, runs_d, s));
+    unsigned runs = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&runs, runs_d, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if ((int64_t)runs > out_cap) return fail(ctx, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %u", (long long)out_cap, runs);
+    HIP_TRY(ctx, exclusive_sum_u32(ctx->sort_tmp.p, &b3, counts, offsets, runs, s));
+    hipLaunchKernelGGL(k_voxel_centroids, dim3((runs + 255) / 256), dim3(256), 0, s, d_pts, (const unsigned *)order,
+                       (const unsigned *)offsets, (const unsigned *)counts, (int)runs, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    *n_out = runs;
+    return ICPMI_OK;
+}
+
 int validate_align(icpmi_ctx *ctx, const void *src, int64_t n_src, const void *tgt, int64_t n_tgt,
                    const icpmi_config *cfg, icpmi_result *result, double *hist, int32_t cap)
 {
@@ -674,7 +745,8 @@ void icpmi_destroy(icpmi_ctx *ctx)
     for (DevBuf *b : {&ctx->cur, &ctx->nrm, &ctx->idx, &ctx->part_d2, &ctx->part_idx, &ctx->partials,
                       &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out,
                       &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin,
-                      &ctx->fb_list, &ctx->sort_keys, &ctx->sort_tmp, &ctx->tgt_sorted, &ctx->frames})
+                      &ctx->fb_list, &ctx->sort_keys, &ctx->sort_tmp, &ctx->tgt_sorted, &ctx->frames, &ctx->vox_keys,
+                      &ctx->vox_vals, &ctx->vox_out})
         release(*b);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -833,6 +905,41 @@ int icpmi_transform_points(icpmi_ctx *ctx, const double transform[16], const dou
     HIP_TRY(ctx, hipStreamSynchronize(s));
     HIP_TRY(ctx, hipGetLastError());
     harvest_profile(ctx);
+    return ICPMI_OK;
+}
+
+int icpmi_voxel_downsample_device(icpmi_ctx *ctx, const double *d_points_xyz, int64_t n, double voxel_size,
+                                  double *d_out_xyz, int64_t out_cap, int64_t *n_out)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!d_points_xyz || !d_out_xyz || !n_out) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n < 0 || n > 700000000) return fail(ctx, ICPMI_ERR_ARG, "n out of range");
+    *n_out = 0;
+    if (n == 0) return ICPMI_OK;
+    return voxel_downsample_device(ctx, d_points_xyz, (int)n, voxel_size, d_out_xyz, out_cap, n_out);
+}
+
+int icpmi_voxel_downsample(icpmi_ctx *ctx, const double *points_xyz, int64_t n, double voxel_size,
+                           double *out_xyz, int64_t out_cap, int64_t *n_out)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!points_xyz || !out_xyz || !n_out) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n < 0 || n > 700000000) return fail(ctx, ICPMI_ERR_ARG, "n out of range");
+    *n_out = 0;
+    if (n == 0) return ICPMI_OK;
+    const size_t bytes = sizeof(double) * 3 * (size_t)n;
+    if ((rc = reserve(ctx, ctx->stage_a, bytes))) return rc;
+    if ((rc = reserve(ctx, ctx->vox_out, bytes))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_a.p, points_xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
+    int64_t rows = 0;
+    if ((rc = voxel_downsample_device(ctx, (const double *)ctx->stage_a.p, (int)n, voxel_size,
+                                      (double *)ctx->vox_out.p, n, &rows)))
+        return rc;
+    if (rows > out_cap) return fail(ctx, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %lld", (long long)out_cap, (long long)rows);
+    HIP_TRY(ctx, hipMemcpy(out_xyz, ctx->vox_out.p, sizeof(double) * 3 * (size_t)rows, hipMemcpyDeviceToHost));
+    *n_out = rows;
     return ICPMI_OK;
 }
 

@@ -17,3 +17,32 @@ hipError_t sort_pairs_u32(void *temp, size_t *temp_bytes, const unsigned *keys_i
 }
 
 } // namespace icpmi
+
+// ---- voxel pre-filter helpers (file_utils.cpp:148-196 on the GPU): 63-bit voxel keys ----------
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace icpmi {
+
+hipError_t sort_pairs_u64(void *temp, size_t *temp_bytes, const unsigned long long *keys_in,
+                          unsigned long long *keys_out, const unsigned *vals_in, unsigned *vals_out,
+                          unsigned n, hipStream_t stream)
+{
+    return rocprim::radix_sort_pairs(temp, *temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, 63u, stream);
+}
+
+// runs of equal keys: counts[r] and *runs_out (device) ; unique keys are written to unique_out
+hipError_t run_lengths_u64(void *temp, size_t *temp_bytes, const unsigned long long *keys, unsigned n,
+                           unsigned long long *unique_out, unsigned *counts_out, unsigned *runs_out,
+                           hipStream_t stream)
+{
+    return rocprim::run_length_encode(temp, *temp_bytes, keys, n, unique_out, counts_out, runs_out, stream);
+}
+
+hipError_t exclusive_sum_u32(void *temp, size_t *temp_bytes, const unsigned *in, unsigned *out, unsigned n,
+                             hipStream_t stream)
+{
+    return rocprim::exclusive_scan(temp, *temp_bytes, in, out, 0u, n, rocprim::plus<unsigned>(), stream);
+}
+
+} // namespace icpmi

@@ -659,6 +659,59 @@ void orc_solve_point_to_plane(const double *src, const double *tgt, const double
 }
 
 /* ------------------------------------------------------------------------- */
+/* Voxel downsampling (src/core/file_utils.cpp:148-196)                      */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    long long x, y, z; /* file_utils.cpp:156 */
+    int index;
+} voxel_ent;
+
+static int voxel_cmp(const void *a, const void *b)
+{
+    const voxel_ent *p = (const voxel_ent *)a, *q = (const voxel_ent *)b;
+    if (p->x != q->x) return p->x < q->x ? -1 : 1;
+    if (p->y != q->y) return p->y < q->y ? -1 : 1;
+    if (p->z != q->z) return p->z < q->z ? -1 : 1;
+    return p->index < q->index ? -1 : (p->index > q->index ? 1 : 0); /* input order inside a voxel */
+}
+
+int orc_voxel_downsample(const double *pts, int n, double voxel_size, double *out)
+{
+    if (voxel_size <= 0) { /* file_utils.cpp:152 */
+        memcpy(out, pts, sizeof(double) * 3 * (size_t)n);
+        return n;
+    }
+    voxel_ent *e = (voxel_ent *)malloc(sizeof(voxel_ent) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) { /* file_utils.cpp:175-181 */
+        e[i].x = (long long)floor(pts[3 * i] / voxel_size);
+        e[i].y = (long long)floor(pts[3 * i + 1] / voxel_size);
+        e[i].z = (long long)floor(pts[3 * i + 2] / voxel_size);
+        e[i].index = i;
+    }
+    qsort(e, (size_t)n, sizeof(voxel_ent), voxel_cmp);
+    int count = 0;
+    for (int a = 0; a < n;) { /* file_utils.cpp:186-193 */
+        int b = a;
+        double cx = 0, cy = 0, cz = 0;
+        while (b < n && e[b].x == e[a].x && e[b].y == e[a].y && e[b].z == e[a].z) {
+            cx += pts[3 * e[b].index];
+            cy += pts[3 * e[b].index + 1];
+            cz += pts[3 * e[b].index + 2];
+            ++b;
+        }
+        const double k = (double)(b - a);
+        out[3 * count] = cx / k;
+        out[3 * count + 1] = cy / k;
+        out[3 * count + 2] = cz / k;
+        ++count;
+        a = b;
+    }
+    free(e);
+    return count;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Driver (icp.hpp:157-258)                                                  */
 /* ------------------------------------------------------------------------- */
 

@@ -64,6 +64,13 @@ void orc_solve_from_sums(const double sums[28], double T_rowmajor[16]);
 /* 3x3 symmetric eigen: eigenvector of the smallest eigenvalue (icp.hpp:55-56). */
 void orc_smallest_eigenvector(const double cov_rowmajor[9], double v[3]);
 
+/* src/core/file_utils.cpp:148-196 (voxel_downsample): centroid of the points of every
+ * occupied voxel, key = floor(coord / voxel_size) per axis, points summed in input order.
+ * The reference emits voxels in std::unordered_map iteration order (implementation-defined);
+ * here they come out sorted by (kx, ky, kz).  Returns the number of voxels (<= n); out_xyz
+ * must hold 3*n doubles.  voxel_size <= 0 copies the input (file_utils.cpp:152). */
+int orc_voxel_downsample(const double *points_xyz, int n, double voxel_size, double *out_xyz);
+
 typedef struct {
     int max_iterations;          /* types.hpp:144 */
     double tolerance;            /* types.hpp:145 */

@@ -57,6 +57,8 @@ def lib():
         L.orc_normal_equations.argtypes = [dp, dp, dp, C.c_int, dp]
         L.orc_solve_from_sums.argtypes = [dp, dp]
         L.orc_smallest_eigenvector.argtypes = [dp, dp]
+        L.orc_voxel_downsample.restype = C.c_int
+        L.orc_voxel_downsample.argtypes = [dp, C.c_int, C.c_double, dp]
         L.orc_icp_config_default.argtypes = [C.POINTER(Config)]
         L.orc_icp_point_to_plane.restype = C.c_int
         L.orc_icp_point_to_plane.argtypes = [dp, C.c_int, dp, C.c_int, C.POINTER(Config), C.c_int,
@@ -159,6 +161,15 @@ def smallest_eigenvector(cov):
     v = np.empty(3)
     lib().orc_smallest_eigenvector(cp, v.ctypes.data_as(C.POINTER(C.c_double)))
     return v
+
+
+def voxel_downsample(points, voxel_size):
+    """file_utils.cpp:148-196; voxels come out sorted by key (the reference's order is
+    implementation-defined)."""
+    p, pp = _d(points)
+    out = np.empty_like(p)
+    c = lib().orc_voxel_downsample(pp, p.shape[0], float(voxel_size), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out[:c].copy()
 
 
 class ICPResult:

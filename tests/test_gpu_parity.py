@@ -262,6 +262,55 @@ def test_host_mirror_api(gpu_ctx, oracle):
     assert (matched == tgt[oidx]).all() and (dist == np.sqrt(od2)).all()
 
 
+# ------------------------------------------------------------------ voxel filter
+@pytest.mark.parametrize("n,voxel,scale,offset", [(1, 0.5, 1.0, 0.0), (1000, 0.5, 10.0, 0.0),
+                                                  (50000, 0.5, 30.0, 0.0), (50000, 0.25, 30.0, -700.0),
+                                                  (20000, 2.0, 30.0, 1.0e5)])
+def test_voxel_downsample_bit_exact(gpu_ctx, oracle, n, voxel, scale, offset):
+    rng = np.random.default_rng(n)
+    pts = rng.uniform(-scale, scale, (n, 3)) + offset
+    got = gpu_ctx.voxel_downsample(pts, voxel)
+    want = oracle.voxel_downsample(pts, voxel)
+    assert got.shape == want.shape and (got == want).all()   # same voxels, same order, same bits
+
+
+def test_voxel_downsample_lidar_frame_and_edge_cases(gpu_ctx, oracle):
+    raw = synth.lidar_frame(0, voxel=None, beams=32, azimuths=900)
+    got = gpu_ctx.voxel_downsample(raw, 0.5)
+    assert (got == oracle.voxel_downsample(raw, 0.5)).all()
+    # as a set it is what the reference's unordered_map version yields (numpy restatement)
+    ref = synth.voxel_centroids(raw, 0.5)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+    # points exactly on voxel boundaries and negative coordinates: floor(), not truncation
+    edge = np.array([[0.0, 0, 0], [0.5, 0, 0], [-0.5, 0, 0], [-1e-12, 0, 0], [0.4999999999, 0, 0], [1.0, 1.0, 1.0]])
+    assert (gpu_ctx.voxel_downsample(edge, 0.5) == oracle.voxel_downsample(edge, 0.5)).all()
+    assert (gpu_ctx.voxel_downsample(edge, 0.0) == edge).all()          # file_utils.cpp:152
+    assert gpu_ctx.voxel_downsample(np.zeros((0, 3)), 0.5).shape == (0, 3)
+    with pytest.raises(capi.IcpError) as e:                              # > 2^21 cells on an axis
+        gpu_ctx.voxel_downsample(np.array([[0.0, 0, 0], [1e7, 0, 0]]), 1e-3)
+    assert e.value.code == capi.ERR_ARG
+    with pytest.raises(capi.IcpError):
+        gpu_ctx.voxel_downsample(np.array([[0.0, 0, 0], [np.nan, 0, 0]]), 0.5)
+
+
+def test_voxel_then_align_on_device(gpu_ctx, oracle):
+    """The stream path of slam_node.cpp:121-138 without leaving HBM: raw scans -> voxel filter
+    -> registration, all on device pointers."""
+    import torch
+    raw_t = synth.lidar_frame(0, voxel=None, beams=32, azimuths=900)
+    raw_s = synth.lidar_frame(1, voxel=None, beams=32, azimuths=900)
+    dev = torch.device("cuda", 0)
+    d_t, d_s = torch.from_numpy(raw_t).to(dev), torch.from_numpy(raw_s).to(dev)
+    o_t, o_s = torch.empty_like(d_t), torch.empty_like(d_s)
+    torch.cuda.synchronize()
+    n_t = gpu_ctx.voxel_downsample_device(d_t.data_ptr(), raw_t.shape[0], 0.5, o_t.data_ptr(), raw_t.shape[0])
+    n_s = gpu_ctx.voxel_downsample_device(d_s.data_ptr(), raw_s.shape[0], 0.5, o_s.data_ptr(), raw_s.shape[0])
+    res, hist = gpu_ctx.align_device(o_s.data_ptr(), n_s, o_t.data_ptr(), n_t, capi.Context.make_config())
+    ref = oracle.icp_point_to_plane(oracle.voxel_downsample(raw_s, 0.5), oracle.voxel_downsample(raw_t, 0.5))
+    check_against(res, hist, ref.transformation, ref.converged, ref.num_iterations, ref.error_history)
+
+
 # ------------------------------------------------------------------ odometry stream (SURVEY 8f N3)
 def test_odometry_stream_matches_oracle(gpu_ctx, oracle):
     """process_frame minus ROS (slam_node.cpp:118-157) over a short synthetic drive: same

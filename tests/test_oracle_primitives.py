@@ -148,3 +148,18 @@ def test_ldlt_zero_pivot_rule(oracle):
     assert np.isfinite(T).all()
     assert abs(T[2, 3] - 0.01) < 1e-12
     assert T[0, 3] == 0 and T[1, 3] == 0  # unobservable translation components -> 0
+
+
+def test_voxel_downsample_matches_numpy_restatement(oracle):
+    """file_utils.cpp:148-196: same voxel set and centroids as an independent numpy grouping."""
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-30, 30, (20000, 3))
+    a = oracle.voxel_downsample(pts, 0.5)
+    b = synth.voxel_centroids(pts, 0.5)
+    assert a.shape == b.shape
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+    keys = np.floor(a / 0.5).astype(np.int64)
+    assert len(np.unique(keys, axis=0)) == len(keys)          # one centroid per voxel
+    assert (oracle.voxel_downsample(pts, 0.0) == pts).all()   # file_utils.cpp:152
+    one = oracle.voxel_downsample(np.array([[0.1, 0.2, 0.3], [0.2, 0.1, 0.4]]), 0.5)
+    np.testing.assert_allclose(one, [[0.15, 0.15, 0.35]], atol=1e-15)
