@@ -52,9 +52,12 @@ namespace icpmi {
 
 constexpr int kTile = 32;                         // queries / targets per MFMA tile
 constexpr int kCols = 32;                         // columns (slots) per split
-constexpr int kSplitTiles = 64;                   // target tiles per split
-constexpr int kSplitTargets = kSplitTiles * kTile;// 2048
-constexpr int kSlotTargets = kSplitTiles;         // 64 targets per (split, column) slot
+#ifndef ICPMI_SPLIT_TILES
+#define ICPMI_SPLIT_TILES 64
+#endif
+constexpr int kSplitTiles = ICPMI_SPLIT_TILES;    // target tiles per split (build-time tunable)
+constexpr int kSplitTargets = kSplitTiles * kTile;// targets per split
+constexpr int kSlotTargets = kSplitTiles;         // targets per (split, column) slot
 constexpr int kChunkTiles = 32;                   // tiles staged in LDS at a time (32 KiB)
 constexpr int kCoarseQT = 2;                      // 32-query tiles per wave
 constexpr int kCoarseWaves = 8;                   // waves per workgroup
@@ -372,8 +375,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
         for (int e = 0; e < CHUNK16 / THREADS; ++e)
             lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
         __syncthreads();
-#pragma unroll 1
-        for (int tt = 0; tt < kChunkTiles; tt += 2) {
+#pragma unroll
+        for (int tt = 0; tt < kChunkTiles; tt += 2) { // fully unrolled: immediate LDS offsets
             const bf16x8 b0 = __builtin_bit_cast(bf16x8, lds[tt * 64 + lane]);
             const bf16x8 b1 = __builtin_bit_cast(bf16x8, lds[(tt + 1) * 64 + lane]);
 #pragma unroll
@@ -778,46 +781,54 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     const double xr = eps + sqrt(eps * eps + (ts + eps * eps + A)); // sqrt(dmax)
     const double dmax = tS >= kBig ? 1.0e300 : xr * xr * (1.0 + 1e-9);
 
-    // bound (b): exact scan of the best slot (two targets per lane)
-    double d0 = kInf, d1 = kInf;
-    int o0 = 0, o1 = 0;
+    // bound (b): exact scan of the best slot (kSlotTargets / 64 targets per lane); when a slot
+    // is a single 64-run the 64 sorted positions after it (the next slot) also tighten the
+    // bound -- those are collected later through the normal path
+    constexpr int kOwn = kSlotTargets / 64 > 0 ? kSlotTargets / 64 : 1;
+    constexpr int kBnd = kOwn > 1 ? kOwn : 2; // runs of 64 used for the bound
+    double dloc[kBnd];
+    int oloc[kBnd];
     {
-        // the best slot (64 targets, one per lane) and the 64 sorted positions after it (the next
-        // slot: only used to tighten the bound, collected later through the normal path)
         const int j0 = (bslot / kCols) * kSplitTargets + (bslot % kCols) * kSlotTargets;
-        const int ja = j0 + lane, jb = j0 + 64 + lane;
-        if (ja < m) {
-            d0 = sqdist(ICPMI_SX(sorted, ms, ja), ICPMI_SY(sorted, ms, ja), ICPMI_SZ(sorted, ms, ja), px, py, pz);
-            o0 = (int)perm[ja];
-        }
-        if (jb < m) {
-            d1 = sqdist(ICPMI_SX(sorted, ms, jb), ICPMI_SY(sorted, ms, jb), ICPMI_SZ(sorted, ms, jb), px, py, pz);
-            o1 = (int)perm[jb];
+#pragma unroll
+        for (int c = 0; c < kBnd; ++c) {
+            const int jj = j0 + 64 * c + lane;
+            dloc[c] = kInf;
+            oloc[c] = 0;
+            if (jj < m) {
+                dloc[c] = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), px, py, pz);
+                oloc[c] = (int)perm[jj];
+            }
         }
     }
-    const double t1 = wave_kth_smallest(d0 < d1 ? d0 : d1, lane, kk);
+    double lbest = dloc[0];
+#pragma unroll
+    for (int c = 1; c < kBnd; ++c) lbest = dloc[c] < lbest ? dloc[c] : lbest;
+    const double t1 = wave_kth_smallest(lbest, lane, kk);
     double T = t1 < dmax ? t1 : dmax;
-    (void)o1;
 
     // candidates: the best slot's targets under T, then every other slot under its split's
     // bound.  If more than kKnnCap turn up, the k-th smallest of those already held is a
     // tighter valid bound: collect again with it (a few rows per cloud).
     const int nsplits = (nslots + kCols - 1) / kCols;
+    static_assert(kSlotTargets <= kKnnCap, "the best slot's targets must fit the candidate list");
     int total = 0;
     for (int attempt = 0; attempt < 4; ++attempt) {
         const double sq = sqrt(T);
         for (int sp = lane; sp < nsplits && sp < kKnnMaxSplits; sp += 64)
             tau_sp[wave][sp] = T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[sp], T, sq);
         __builtin_amdgcn_wave_barrier();
-        {
-            const bool k0 = d0 <= T;
-            const unsigned long long m0 = __ballot(k0);
-            if (k0) {
-                const int pos = __popcll(m0 & ((1ull << lane) - 1ull));
-                cand_d[wave][pos] = d0; // at most 64 <= kKnnCap
-                cand_j[wave][pos] = o0;
+        total = 0;
+#pragma unroll
+        for (int c = 0; c < kOwn; ++c) { // the best slot's own targets (at most kSlotTargets <= kKnnCap)
+            const bool keep = dloc[c] <= T;
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+                const int pos = total + __popcll(km & ((1ull << lane) - 1ull));
+                cand_d[wave][pos] = dloc[c];
+                cand_j[wave][pos] = oloc[c];
             }
-            total = __popcll(m0);
+            total += __popcll(km);
         }
         // flags of the register-resident slots first (static indexing), as a bit mask
         unsigned regflags = 0u;
