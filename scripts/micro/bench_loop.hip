@@ -7,11 +7,11 @@
 using namespace icpmi;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
-template <int VAR, int QT, int WAVES>
+template <int VAR, int QT, int WAVES, int PADKB = 0>
 __global__ __launch_bounds__(64 * WAVES) void k_loop(const float4 *__restrict__ Bpack, float *out, int nevertrue)
 {
     constexpr int THREADS = 64 * WAVES;
-    __shared__ float4 ldsB[32 * 64];
+    __shared__ float4 ldsB[32 * 64 + PADKB * 64]; // PADKB KiB of padding limits workgroups per CU
     const int s = blockIdx.y;
     for (int e = 0; e < (32 * 64) / THREADS; ++e) ldsB[threadIdx.x + e * THREADS] = Bpack[(size_t)s * 2048 + threadIdx.x + e * THREADS];
     const int lane = threadIdx.x & 63;
@@ -294,6 +294,8 @@ int main()
     const double ideal_ms = (double)n * m / 256.0 * 32.0 / 1024.0 / 2.4e9 * 1e3;
 #define RUN(VAR, QT, W) { const int qpb = 16 * QT * W; float ms = timeit([&] { hipLaunchKernelGGL((k_loop<VAR, QT, W>), dim3((n + qpb - 1) / qpb, splits), dim3(64 * W), 0, 0, bp, out, -12345); }); printf("var %d QT=%d W=%d : %.3f ms  (%.1f%%)\n", VAR, QT, W, ms, 100 * ideal_ms / ms); }
 #define RUN32(VAR, QT, W) { const int qpb = 32 * QT * W; float ms = timeit([&] { hipLaunchKernelGGL((k_loop<VAR, QT, W>), dim3((n + qpb - 1) / qpb, splits), dim3(64 * W), 0, 0, bp, out, -12345); }); printf("var %d QT32=%d W=%d : %.3f ms  (%.1f%%)\n", VAR, QT, W, ms, 100 * ideal_ms / ms); }
+#define RUNP(VAR, QT, W, PAD) { const int qpb = 32 * QT * W; float ms = timeit([&] { hipLaunchKernelGGL((k_loop<VAR, QT, W, PAD>), dim3((n + qpb - 1) / qpb, splits), dim3(64 * W), 0, 0, bp, out, -12345); }); printf("var %d QT32=%d W=%d padKB=%d : %.3f ms  (%.1f%%)\n", VAR, QT, W, PAD, ms, 100 * ideal_ms / ms); }
+    RUNP(10, 2, 4, 100) RUNP(11, 2, 4, 100) RUNP(11, 4, 4, 100) RUNP(10, 4, 4, 100) RUNP(11, 2, 8, 100) RUNP(11, 4, 8, 100) RUNP(11, 2, 4, 40) RUNP(11, 4, 4, 40)
     RUN(6, 4, 8) RUN(6, 8, 8) RUN32(10, 2, 8) RUN32(11, 2, 8) RUN32(10, 4, 8) RUN32(11, 4, 8) RUN32(10, 2, 4) RUN32(11, 2, 4) RUN32(10, 1, 8)
     return 0;
 }
