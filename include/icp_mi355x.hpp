@@ -216,6 +216,23 @@ inline ICPResult icp_point_to_plane(const PointCloud &source, const PointCloud &
                               target.size(), config);
 }
 
+// Same call shape as slam::voxel_downsample (src/core/file_utils.cpp:148-196); voxels come
+// out sorted by key (the reference's order is std::unordered_map iteration order).
+inline PointCloud voxel_downsample(Context &ctx, const PointCloud &points, double voxel_size)
+{
+    std::vector<double> out(3 * points.size());
+    int64_t rows = 0;
+    int rc = icpmi_voxel_downsample(ctx.get(), points.data(), static_cast<int64_t>(points.size()), voxel_size,
+                                    out.data(), static_cast<int64_t>(points.size()), &rows);
+    if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx.get()));
+    out.resize(3 * static_cast<std::size_t>(rows));
+    return PointCloud(std::move(out));
+}
+inline PointCloud voxel_downsample(const PointCloud &points, double voxel_size)
+{
+    return voxel_downsample(default_context(), points, voxel_size);
+}
+
 // `ICP(config).align(source, target)`: the facade BASELINE.json's north_star names.
 class ICP {
 public:

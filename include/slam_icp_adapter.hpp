@@ -79,6 +79,22 @@ inline ICPResult icp_point_to_plane(const PointCloud &source, const PointCloud &
     return result;
 }
 
+// Drop-in for slam::voxel_downsample (src/core/file_utils.cpp:148-196; callers
+// slam_node.cpp:69,122).  Named differently so that it can coexist with the reference's own
+// definition in file_utils.cpp; on any library error the input is returned unchanged.
+inline PointCloud::Matrix voxel_downsample_mi355x(const PointCloud::Matrix &points, double voxel_size)
+{
+    icpmi_ctx *ctx = icp_mi355x_detail::context();
+    if (!ctx || points.rows() == 0) return points;
+    PointCloud::Matrix out(points.rows(), 3);
+    int64_t rows = 0;
+    if (icpmi_voxel_downsample(ctx, points.data(), static_cast<int64_t>(points.rows()), voxel_size, out.data(),
+                               static_cast<int64_t>(points.rows()), &rows) != ICPMI_OK)
+        return points;
+    out.conservativeResize(rows, 3);
+    return out;
+}
+
 // The facade named in BASELINE.json's north_star.
 struct ICP {
     ICPConfig config;
