@@ -143,6 +143,17 @@ int icpmi_voxel_downsample_device(icpmi_ctx *ctx, const double *d_points_xyz, in
                                   double voxel_size, double *d_out_xyz, int64_t out_cap,
                                   int64_t *n_out);
 
+/* Replaces ScanContext::compute (core/scan_context.hpp:44-82): 20 rings x 60 sectors max-height
+ * descriptor, row-major desc_out[ring * 60 + sector], empty bins 0. */
+#define ICPMI_SC_RINGS 20
+#define ICPMI_SC_SECTORS 60
+int icpmi_scan_context(icpmi_ctx *ctx, const double *cloud_xyz, int64_t n, double *desc_out /* 1200 */);
+/* Replaces the loop of ScanContext::distance calls in LoopClosureDetector::detect
+ * (core/loop_closure.hpp:78-89, core/scan_context.hpp:90-142): dist_out[i] = min over the 60
+ * column shifts of 1 - cosine(query, hist_descs + 1200 * i). */
+int icpmi_scan_context_distances(icpmi_ctx *ctx, const double *query_desc, const double *hist_descs,
+                                 int64_t count, double *dist_out);
+
 /* Multi-GPU (new; the reference has no distributed path).  One process per GPU.  Rank 0
  * obtains an id, the host distributes it (e.g. torch.distributed broadcast), every rank
  * calls icpmi_comm_init.  Afterwards icpmi_align* treats `source` as this rank's shard

@@ -22,6 +22,7 @@ EXPORTS = [
     "icpmi_nearest_batch", "icpmi_estimate_normals", "icpmi_solve_point_to_plane",
     "icpmi_transform_points", "icpmi_comm_unique_id", "icpmi_comm_init", "icpmi_comm_finalize",
     "icpmi_comm_init_callbacks", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
+    "icpmi_scan_context", "icpmi_scan_context_distances",
     "icpmi_reset_profile", "icpmi_get_profile",
 ]
 
@@ -99,6 +100,8 @@ def load_library(path=None):
     i64p = C.POINTER(C.c_int64)
     L.icpmi_voxel_downsample.argtypes = [vp, dp, C.c_int64, C.c_double, dp, C.c_int64, i64p]
     L.icpmi_voxel_downsample_device.argtypes = [vp, vp, C.c_int64, C.c_double, vp, C.c_int64, i64p]
+    L.icpmi_scan_context.argtypes = [vp, dp, C.c_int64, dp]
+    L.icpmi_scan_context_distances.argtypes = [vp, dp, dp, C.c_int64, dp]
     L.icpmi_comm_unique_id.argtypes = [vp, vp]
     L.icpmi_comm_init.argtypes = [vp, C.c_int32, C.c_int32, vp]
     L.icpmi_comm_finalize.argtypes = [vp]
@@ -220,6 +223,21 @@ class Context:
         self._check(self._lib.icpmi_voxel_downsample_device(self._h, C.c_void_p(src_ptr), n, float(voxel_size),
                                                             C.c_void_p(out_ptr), out_cap, C.byref(n_out)))
         return n_out.value
+
+    def scan_context(self, cloud):
+        """scan_context.hpp:44-82 -> 20 x 60 descriptor"""
+        pts = _f64(cloud)
+        out = np.empty(1200)
+        self._check(self._lib.icpmi_scan_context(self._h, _dp(pts), pts.shape[0], _dp(out)))
+        return out.reshape(20, 60)
+
+    def scan_context_distances(self, query_desc, hist_descs):
+        """scan_context.hpp:90-142 for one query against a stack of descriptors"""
+        q = np.ascontiguousarray(query_desc, dtype=np.float64).reshape(1200)
+        h = np.ascontiguousarray(hist_descs, dtype=np.float64).reshape(-1, 1200)
+        out = np.empty(h.shape[0])
+        self._check(self._lib.icpmi_scan_context_distances(self._h, _dp(q), _dp(h), h.shape[0], _dp(out)))
+        return out
 
     # multi-GPU
     def comm_unique_id(self):

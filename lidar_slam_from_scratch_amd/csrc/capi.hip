@@ -26,6 +26,7 @@
 #include "kernels.h"
 #include "nn_mfma.h"
 #include "voxel.h"
+#include "scan_context.h"
 
 using namespace icpmi;
 
@@ -940,6 +941,48 @@ int icpmi_voxel_downsample(icpmi_ctx *ctx, const double *points_xyz, int64_t n, 
     if (rows > out_cap) return fail(ctx, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %lld", (long long)out_cap, (long long)rows);
     HIP_TRY(ctx, hipMemcpy(out_xyz, ctx->vox_out.p, sizeof(double) * 3 * (size_t)rows, hipMemcpyDeviceToHost));
     *n_out = rows;
+    return ICPMI_OK;
+}
+
+int icpmi_scan_context(icpmi_ctx *ctx, const double *cloud_xyz, int64_t n, double *desc_out)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!cloud_xyz || !desc_out) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n < 0 || n > 700000000) return fail(ctx, ICPMI_ERR_ARG, "n out of range");
+    const size_t bytes = sizeof(double) * 3 * (size_t)std::max<int64_t>(n, 1);
+    if ((rc = reserve(ctx, ctx->stage_a, bytes))) return rc;
+    if ((rc = reserve(ctx, ctx->vox_out, sizeof(double) * kScCells))) return rc;
+    hipStream_t s = ctx->stream;
+    if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_a.p, cloud_xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_scan_context, dim3(1), dim3(1024), 0, s, (const double *)ctx->stage_a.p, (int)n,
+                       (double *)ctx->vox_out.p);
+    HIP_TRY(ctx, hipMemcpyAsync(desc_out, ctx->vox_out.p, sizeof(double) * kScCells, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipGetLastError());
+    return ICPMI_OK;
+}
+
+int icpmi_scan_context_distances(icpmi_ctx *ctx, const double *query_desc, const double *hist_descs,
+                                 int64_t count, double *dist_out)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!query_desc || (count > 0 && (!hist_descs || !dist_out))) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (count < 0 || count > 100000000) return fail(ctx, ICPMI_ERR_ARG, "count out of range");
+    if (count == 0) return ICPMI_OK;
+    const size_t hb = sizeof(double) * kScCells * (size_t)count;
+    if ((rc = reserve(ctx, ctx->stage_a, hb))) return rc;
+    if ((rc = reserve(ctx, ctx->stage_b, sizeof(double) * kScCells))) return rc;
+    if ((rc = reserve(ctx, ctx->vox_out, sizeof(double) * (size_t)count))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_a.p, hist_descs, hb, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_b.p, query_desc, sizeof(double) * kScCells, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sc_distances, dim3((unsigned)count), dim3(64), 0, s, (const double *)ctx->stage_b.p,
+                       (const double *)ctx->stage_a.p, (int)count, (double *)ctx->vox_out.p);
+    HIP_TRY(ctx, hipMemcpyAsync(dist_out, ctx->vox_out.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;
 }
 

@@ -712,6 +712,63 @@ int orc_voxel_downsample(const double *pts, int n, double voxel_size, double *ou
 }
 
 /* ------------------------------------------------------------------------- */
+/* Scan Context (scan_context.hpp)                                           */
+/* ------------------------------------------------------------------------- */
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+void orc_scan_context(const double *cloud, int n, double *desc)
+{
+    const int R = ORC_SC_RINGS, S = ORC_SC_SECTORS;
+    const double max_range = 80.0; /* scan_context.hpp:29 */
+    for (int e = 0; e < R * S; ++e) desc[e] = -DBL_MAX; /* :45 */
+    const double ring_size = max_range / R;         /* :47 */
+    const double sector_size = 2.0 * M_PI / S;      /* :48 */
+    for (int i = 0; i < n; ++i) {
+        const double x = cloud[3 * i], y = cloud[3 * i + 1], z = cloud[3 * i + 2];
+        const double range = sqrt(x * x + y * y);   /* :56 */
+        const double angle = atan2(y, x) + M_PI;    /* :57 */
+        if (range > max_range || range < 0.1) continue; /* :59 */
+        int ring = (int)(range / ring_size);        /* :62 */
+        int sector = (int)(angle / sector_size);    /* :63 */
+        ring = ring < 0 ? 0 : (ring > R - 1 ? R - 1 : ring);       /* :65 */
+        sector = sector < 0 ? 0 : (sector > S - 1 ? S - 1 : sector); /* :66 */
+        if (z > desc[ring * S + sector]) desc[ring * S + sector] = z; /* :69-71 */
+    }
+    for (int e = 0; e < R * S; ++e)
+        if (desc[e] < -1000) desc[e] = 0; /* :75-81 */
+}
+
+/* scan_context.hpp:121-142 */
+static double sc_shifted_distance(const double *a, const double *b, int shift)
+{
+    const int R = ORC_SC_RINGS, S = ORC_SC_SECTORS;
+    double sum_ab = 0, sum_aa = 0, sum_bb = 0;
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < S; ++j) {
+            const double va = a[i * S + j], vb = b[i * S + (j + shift) % S];
+            sum_ab += va * vb;
+            sum_aa += va * va;
+            sum_bb += vb * vb;
+        }
+    const double norm = sqrt(sum_aa) * sqrt(sum_bb);
+    if (norm < 1e-10) return 1.0;
+    return 1.0 - sum_ab / norm;
+}
+
+double orc_scan_context_distance(const double *a, const double *b)
+{
+    double best = DBL_MAX; /* scan_context.hpp:91 */
+    for (int shift = 0; shift < ORC_SC_SECTORS; ++shift) {
+        const double d = sc_shifted_distance(a, b, shift);
+        if (d < best) best = d;
+    }
+    return best;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Driver (icp.hpp:157-258)                                                  */
 /* ------------------------------------------------------------------------- */
 

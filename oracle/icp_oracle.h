@@ -71,6 +71,14 @@ void orc_smallest_eigenvector(const double cov_rowmajor[9], double v[3]);
  * must hold 3*n doubles.  voxel_size <= 0 copies the input (file_utils.cpp:152). */
 int orc_voxel_downsample(const double *points_xyz, int n, double voxel_size, double *out_xyz);
 
+/* scan_context.hpp:44-82 (ScanContext::compute): 20 rings x 60 sectors max-height descriptor,
+ * row-major desc[ring*60 + sector]; empty bins 0. */
+#define ORC_SC_RINGS 20
+#define ORC_SC_SECTORS 60
+void orc_scan_context(const double *cloud_xyz, int n, double *desc /* 20*60 */);
+/* scan_context.hpp:90-101,121-142 (distance): min over the 60 column shifts of 1 - cosine. */
+double orc_scan_context_distance(const double *a, const double *b);
+
 typedef struct {
     int max_iterations;          /* types.hpp:144 */
     double tolerance;            /* types.hpp:145 */

@@ -59,6 +59,9 @@ def lib():
         L.orc_smallest_eigenvector.argtypes = [dp, dp]
         L.orc_voxel_downsample.restype = C.c_int
         L.orc_voxel_downsample.argtypes = [dp, C.c_int, C.c_double, dp]
+        L.orc_scan_context.argtypes = [dp, C.c_int, dp]
+        L.orc_scan_context_distance.restype = C.c_double
+        L.orc_scan_context_distance.argtypes = [dp, dp]
         L.orc_icp_config_default.argtypes = [C.POINTER(Config)]
         L.orc_icp_point_to_plane.restype = C.c_int
         L.orc_icp_point_to_plane.argtypes = [dp, C.c_int, dp, C.c_int, C.POINTER(Config), C.c_int,
@@ -170,6 +173,22 @@ def voxel_downsample(points, voxel_size):
     out = np.empty_like(p)
     c = lib().orc_voxel_downsample(pp, p.shape[0], float(voxel_size), out.ctypes.data_as(C.POINTER(C.c_double)))
     return out[:c].copy()
+
+
+def scan_context(cloud):
+    """scan_context.hpp:44-82 -> 20 x 60 descriptor"""
+    p, pp = _d(cloud)
+    out = np.empty(1200)
+    lib().orc_scan_context(pp, p.shape[0], out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out.reshape(20, 60)
+
+
+def scan_context_distance(a, b):
+    """scan_context.hpp:90-101"""
+    a_ = np.ascontiguousarray(a, dtype=np.float64).reshape(1200)
+    b_ = np.ascontiguousarray(b, dtype=np.float64).reshape(1200)
+    return lib().orc_scan_context_distance(a_.ctypes.data_as(C.POINTER(C.c_double)),
+                                           b_.ctypes.data_as(C.POINTER(C.c_double)))
 
 
 class ICPResult:

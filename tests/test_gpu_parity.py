@@ -312,6 +312,58 @@ def test_voxel_then_align_on_device(gpu_ctx, oracle):
     check_against(res, hist, ref.transformation, ref.converged, ref.num_iterations, ref.error_history)
 
 
+# ------------------------------------------------------------------ scan context + loop closure
+def test_scan_context_bit_exact(gpu_ctx, oracle):
+    frames = [synth.lidar_frame(f, beams=32, azimuths=900) for f in (0, 1, 7, 30)]
+    descs = [gpu_ctx.scan_context(f) for f in frames]
+    for f, d in zip(frames, descs):
+        assert (d == oracle.scan_context(f)).all()
+    rng = np.random.default_rng(0)
+    wild = np.c_[rng.uniform(-120, 120, (5000, 2)), rng.uniform(-3, 20, 5000)]   # beyond 80 m, near 0.1 m
+    wild[:50, :2] *= 1e-3
+    assert (gpu_ctx.scan_context(wild) == oracle.scan_context(wild)).all()
+    assert (gpu_ctx.scan_context(np.zeros((0, 3))) == 0).all()
+    hist = np.stack(descs[1:] + [np.zeros((20, 60))])
+    got = gpu_ctx.scan_context_distances(descs[0], hist)
+    want = [oracle.scan_context_distance(descs[0], h) for h in hist]
+    assert (got == np.array(want)).all()
+    assert got[-1] == 1.0                                     # zero-norm descriptor -> 1 (scan_context.hpp:138)
+    assert gpu_ctx.scan_context_distances(descs[0], descs[0][None])[0] < 1e-15
+
+
+def test_loop_closure_detector_matches_oracle(gpu_ctx, oracle):
+    """LoopClosureDetector::detect (loop_closure.hpp:66-126) with the GPU behind it against
+    the same host logic with the oracle behind it: a short drive that comes back to its
+    start."""
+    from lidar_slam_from_scratch_amd import loop_closure as lc
+
+    class OracleBackend:
+        def scan_context(self, cloud):
+            return oracle.scan_context(cloud)
+
+        def distances(self, q, hist):
+            return np.array([oracle.scan_context_distance(q, h) for h in hist])
+
+        def align(self, s, t, mi, tol):
+            return oracle.icp_point_to_plane(s, t, mi, tol, 1e-9)
+
+    order = [0, 2, 4, 6, 8, 10, 12, 1, 3]      # frames 1 and 3 revisit the start of the drive
+    clouds = [synth.lidar_frame(f, beams=32, azimuths=900) for f in order]
+    cfg = lc.LoopClosureConfig(frame_gap=5, sc_distance_threshold=0.2, icp_fitness_threshold=0.3)
+    dets = [lc.LoopClosureDetector(lc.GpuBackend(gpu_ctx), cfg), lc.LoopClosureDetector(OracleBackend(), cfg)]
+    found = [[], []]
+    for k, c in enumerate(clouds):
+        for d, out in zip(dets, found):
+            d.add_frame(c, k)
+            out.extend(d.detect())
+    assert len(found[0]) == len(found[1]) and len(found[0]) >= 1
+    for a, b in zip(found[0], found[1]):
+        assert (a.query_frame, a.match_frame) == (b.query_frame, b.match_frame)
+        assert a.scan_context_distance == b.scan_context_distance
+        dt, dr = synth.pose_delta(a.transform, b.transform)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and abs(a.icp_fitness - b.icp_fitness) < 1e-9
+
+
 # ------------------------------------------------------------------ odometry stream (SURVEY 8f N3)
 def test_odometry_stream_matches_oracle(gpu_ctx, oracle):
     """process_frame minus ROS (slam_node.cpp:118-157) over a short synthetic drive: same

@@ -163,3 +163,25 @@ def test_voxel_downsample_matches_numpy_restatement(oracle):
     assert (oracle.voxel_downsample(pts, 0.0) == pts).all()   # file_utils.cpp:152
     one = oracle.voxel_downsample(np.array([[0.1, 0.2, 0.3], [0.2, 0.1, 0.4]]), 0.5)
     np.testing.assert_allclose(one, [[0.15, 0.15, 0.35]], atol=1e-15)
+
+
+def test_scan_context_against_numpy(oracle):
+    """scan_context.hpp:44-82 and :90-142 against an independent numpy statement."""
+    f0 = synth.lidar_frame(0, beams=32, azimuths=600)
+    f1 = synth.lidar_frame(5, beams=32, azimuths=600)
+    a, b = oracle.scan_context(f0), oracle.scan_context(f1)
+    x, y, z = f0.T
+    r = np.sqrt(x * x + y * y)
+    ang = np.arctan2(y, x) + np.pi
+    keep = ~((r > 80.0) | (r < 0.1))
+    ri = np.clip((r / 4.0).astype(int), 0, 19)
+    si = np.clip((ang / (2 * np.pi / 60)).astype(int), 0, 59)
+    d = np.full((20, 60), -1e308)
+    for k in np.nonzero(keep)[0]:
+        d[ri[k], si[k]] = max(d[ri[k], si[k]], z[k])
+    d[d < -1000] = 0
+    assert (d == a).all()
+    dist = min(1.0 - (a * np.roll(b, -s, axis=1)).sum() / (np.linalg.norm(a) * np.linalg.norm(b)) for s in range(60))
+    assert abs(oracle.scan_context_distance(a, b) - dist) < 1e-12
+    assert oracle.scan_context_distance(a, a) < 1e-15
+    assert oracle.scan_context_distance(a, np.zeros((20, 60))) == 1.0
