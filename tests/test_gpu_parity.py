@@ -313,14 +313,26 @@ def test_voxel_then_align_on_device(gpu_ctx, oracle):
 
 
 # ------------------------------------------------------------------ scan context + loop closure
+def _off_sector_boundaries(cloud):
+    """Drop points whose azimuth is within 1e-9 of a sector boundary: there the sector depends
+    on the last ulp of atan2, which no two libms agree on (glibc on the CPU, OCML on the GPU;
+    the synthetic scanner shoots rays exactly at multiples of 2*pi/900)."""
+    q = (np.arctan2(cloud[:, 1], cloud[:, 0]) + np.pi) / (2 * np.pi / 60)
+    return cloud[np.abs(q - np.round(q)) > 1e-9]
+
+
 def test_scan_context_bit_exact(gpu_ctx, oracle):
-    frames = [synth.lidar_frame(f, beams=32, azimuths=900) for f in (0, 1, 7, 30)]
+    raw = [synth.lidar_frame(f, beams=32, azimuths=900) for f in (0, 1, 7, 30)]
+    for f in raw:       # unfiltered: at most a boundary point or two may land in the next sector
+        assert (gpu_ctx.scan_context(f) != oracle.scan_context(f)).sum() <= 2
+    frames = [_off_sector_boundaries(f) for f in raw]
     descs = [gpu_ctx.scan_context(f) for f in frames]
     for f, d in zip(frames, descs):
         assert (d == oracle.scan_context(f)).all()
     rng = np.random.default_rng(0)
     wild = np.c_[rng.uniform(-120, 120, (5000, 2)), rng.uniform(-3, 20, 5000)]   # beyond 80 m, near 0.1 m
     wild[:50, :2] *= 1e-3
+    wild = _off_sector_boundaries(wild)
     assert (gpu_ctx.scan_context(wild) == oracle.scan_context(wild)).all()
     assert (gpu_ctx.scan_context(np.zeros((0, 3))) == 0).all()
     hist = np.stack(descs[1:] + [np.zeros((20, 60))])
@@ -348,7 +360,7 @@ def test_loop_closure_detector_matches_oracle(gpu_ctx, oracle):
             return oracle.icp_point_to_plane(s, t, mi, tol, 1e-9)
 
     order = [0, 2, 4, 6, 8, 10, 12, 1, 3]      # frames 1 and 3 revisit the start of the drive
-    clouds = [synth.lidar_frame(f, beams=32, azimuths=900) for f in order]
+    clouds = [_off_sector_boundaries(synth.lidar_frame(f, beams=32, azimuths=900)) for f in order]
     cfg = lc.LoopClosureConfig(frame_gap=5, sc_distance_threshold=0.2, icp_fitness_threshold=0.3)
     dets = [lc.LoopClosureDetector(lc.GpuBackend(gpu_ctx), cfg), lc.LoopClosureDetector(OracleBackend(), cfg)]
     found = [[], []]
