@@ -143,6 +143,14 @@ int icpmi_voxel_downsample_device(icpmi_ctx *ctx, const double *d_points_xyz, in
                                   double voxel_size, double *d_out_xyz, int64_t out_cap,
                                   int64_t *n_out);
 
+/* Replaces load_ply / load_bin (slam_viz/src/core/file_utils.cpp:20-108, 115-141; the node
+ * calls load_ply at slam_node.cpp:69,121): a path ending in ".bin" is read as KITTI
+ * (x, y, z, intensity float32, intensity dropped), anything else as PLY with the reference's
+ * header rules.  Host-side only (no context, no device).  Two-call pattern: with out_xyz ==
+ * NULL only *n_out is set.  A file that cannot be opened returns ICPMI_ERR_ARG (the
+ * reference throws std::runtime_error). */
+int icpmi_load_cloud(const char *path, double *out_xyz, int64_t cap, int64_t *n_out);
+
 /* Replaces ScanContext::compute (core/scan_context.hpp:44-82): 20 rings x 60 sectors max-height
  * descriptor, row-major desc_out[ring * 60 + sector], empty bins 0. */
 #define ICPMI_SC_RINGS 20

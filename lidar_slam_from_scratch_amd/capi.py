@@ -22,7 +22,7 @@ EXPORTS = [
     "icpmi_nearest_batch", "icpmi_estimate_normals", "icpmi_solve_point_to_plane",
     "icpmi_transform_points", "icpmi_comm_unique_id", "icpmi_comm_init", "icpmi_comm_finalize",
     "icpmi_comm_init_callbacks", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
-    "icpmi_scan_context", "icpmi_scan_context_distances",
+    "icpmi_scan_context", "icpmi_scan_context_distances", "icpmi_load_cloud",
     "icpmi_reset_profile", "icpmi_get_profile",
 ]
 
@@ -100,6 +100,7 @@ def load_library(path=None):
     i64p = C.POINTER(C.c_int64)
     L.icpmi_voxel_downsample.argtypes = [vp, dp, C.c_int64, C.c_double, dp, C.c_int64, i64p]
     L.icpmi_voxel_downsample_device.argtypes = [vp, vp, C.c_int64, C.c_double, vp, C.c_int64, i64p]
+    L.icpmi_load_cloud.argtypes = [C.c_char_p, dp, C.c_int64, i64p]
     L.icpmi_scan_context.argtypes = [vp, dp, C.c_int64, dp]
     L.icpmi_scan_context_distances.argtypes = [vp, dp, dp, C.c_int64, dp]
     L.icpmi_comm_unique_id.argtypes = [vp, vp]
@@ -112,6 +113,20 @@ def load_library(path=None):
         getattr(L, name)  # raises AttributeError if a declared symbol is not exported
     _LIB = L
     return L
+
+
+def load_cloud(path):
+    """load_ply / load_bin (file_utils.cpp:20-141) through the library: N x 3 fp64."""
+    L = load_library()
+    n = C.c_int64(0)
+    rc = L.icpmi_load_cloud(os.fsencode(path), None, 0, C.byref(n))
+    if rc != OK:
+        raise IcpError(rc, L.icpmi_last_error(None).decode())
+    out = np.empty((n.value, 3))
+    rc = L.icpmi_load_cloud(os.fsencode(path), out.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n))
+    if rc != OK:
+        raise IcpError(rc, L.icpmi_last_error(None).decode())
+    return out
 
 
 def _f64(a, cols=3):

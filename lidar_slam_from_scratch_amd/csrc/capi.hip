@@ -944,6 +944,110 @@ int icpmi_voxel_downsample(icpmi_ctx *ctx, const double *points_xyz, int64_t n, 
     return ICPMI_OK;
 }
 
+// ---- on-disk formats: host-side, no device work ------------------
+// KITTI .bin: x, y, z, intensity as float32, intensity dropped (file_utils.cpp:115-141).
+// PLY: header parse as file_utils.cpp:31-60 (every `property` line counts towards the vertex
+// stride, whatever element it belongs to -- like the reference); binary payload read as
+// little-endian float32 at the x/y/z offsets whatever the declared type or endianness
+// (file_utils.cpp:87-98); ASCII payload: first three numbers of each line (file_utils.cpp:100-104).
+int icpmi_load_cloud(const char *path, double *out_xyz, int64_t cap, int64_t *n_out)
+{
+    if (!path || !n_out) return fail(nullptr, ICPMI_ERR_NULL, "null argument");
+    *n_out = 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(nullptr, ICPMI_ERR_ARG, "Cannot open file: %s", path); // file_utils.cpp:22-24
+    struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
+    const size_t len = strlen(path);
+    if (len >= 4 && strcmp(path + len - 4, ".bin") == 0) {
+        fseek(f, 0, SEEK_END);
+        const long size = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        const int64_t n = size / (4 * (long)sizeof(float)); // file_utils.cpp:127
+        *n_out = n;
+        if (!out_xyz) return ICPMI_OK;
+        if (cap < n) return fail(nullptr, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %lld", (long long)cap, (long long)n);
+        std::vector<float> buf(4 * 4096);
+        for (int64_t i = 0; i < n;) {
+            const size_t want = (size_t)std::min<int64_t>(4096, n - i);
+            const size_t got = fread(buf.data(), 4 * sizeof(float), want, f);
+            for (size_t k = 0; k < got; ++k)
+                for (int a = 0; a < 3; ++a) out_xyz[3 * (i + k) + a] = (double)buf[4 * k + a];
+            for (size_t k = got; k < want; ++k)
+                for (int a = 0; a < 3; ++a) out_xyz[3 * (i + k) + a] = 0.0;
+            i += want;
+        }
+        return ICPMI_OK;
+    }
+    // PLY header
+    std::string line;
+    auto getline = [&](std::string &s) -> bool {
+        s.clear();
+        int ch;
+        while ((ch = fgetc(f)) != EOF) {
+            if (ch == '\n') return true;
+            s.push_back((char)ch);
+        }
+        return !s.empty();
+    };
+    long num_vertices = 0;
+    bool is_binary = false;
+    std::vector<std::pair<std::string, std::string>> props;
+    while (getline(line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back(); // file_utils.cpp:34-36
+        char tok[64] = "", a[64] = "", b[64] = "";
+        const int nt = sscanf(line.c_str(), "%63s %63s %63s", tok, a, b);
+        if (nt < 1) continue;
+        if (!strcmp(tok, "format")) {
+            if (!strcmp(a, "binary_little_endian") || !strcmp(a, "binary_big_endian")) is_binary = true;
+        } else if (!strcmp(tok, "element")) {
+            if (!strcmp(a, "vertex")) num_vertices = nt >= 3 ? atol(b) : 0;
+        } else if (!strcmp(tok, "property")) {
+            props.emplace_back(std::string(b), std::string(a)); // (name, dtype), file_utils.cpp:54-56
+        } else if (!strcmp(tok, "end_header")) {
+            break;
+        }
+    }
+    auto type_size = [](const std::string &t) -> size_t { // file_utils.cpp:63-70
+        if (t == "float" || t == "float32") return 4;
+        if (t == "double" || t == "float64") return 8;
+        if (t == "uchar" || t == "uint8" || t == "char" || t == "int8") return 1;
+        if (t == "ushort" || t == "uint16" || t == "short" || t == "int16") return 2;
+        if (t == "uint" || t == "uint32" || t == "int" || t == "int32") return 4;
+        return 4;
+    };
+    size_t stride = 0, xo = 0, yo = 0, zo = 0;
+    for (auto &pr : props) {
+        if (pr.first == "x") xo = stride;
+        else if (pr.first == "y") yo = stride;
+        else if (pr.first == "z") zo = stride;
+        stride += type_size(pr.second);
+    }
+    const int64_t n = num_vertices > 0 ? num_vertices : 0;
+    *n_out = n;
+    if (!out_xyz) return ICPMI_OK;
+    if (cap < n) return fail(nullptr, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %lld", (long long)cap, (long long)n);
+    if (is_binary) {
+        if (stride < 4 || xo + 4 > stride || yo + 4 > stride || zo + 4 > stride)
+            return fail(nullptr, ICPMI_ERR_ARG, "PLY vertex layout has no float x/y/z");
+        std::vector<char> buf(stride);
+        for (int64_t i = 0; i < n; ++i) {
+            if (fread(buf.data(), 1, stride, f) != stride) memset(buf.data(), 0, stride);
+            float v[3];
+            memcpy(&v[0], buf.data() + xo, 4);
+            memcpy(&v[1], buf.data() + yo, 4);
+            memcpy(&v[2], buf.data() + zo, 4);
+            for (int a2 = 0; a2 < 3; ++a2) out_xyz[3 * i + a2] = (double)v[a2];
+        }
+    } else {
+        for (int64_t i = 0; i < n; ++i) {
+            double v[3] = {0, 0, 0};
+            if (getline(line)) sscanf(line.c_str(), "%lf %lf %lf", &v[0], &v[1], &v[2]);
+            for (int a2 = 0; a2 < 3; ++a2) out_xyz[3 * i + a2] = v[a2];
+        }
+    }
+    return ICPMI_OK;
+}
+
 int icpmi_scan_context(icpmi_ctx *ctx, const double *cloud_xyz, int64_t n, double *desc_out)
 {
     int rc;

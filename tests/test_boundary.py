@@ -110,3 +110,39 @@ def test_cpp_adapter_compiles_against_a_minimal_cloud_type(tmp_path):
                            "-o", str(exe), build.LIB_PATH, "-Wl,-rpath," + os.path.dirname(build.LIB_PATH),
                            "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"])
     assert subprocess.call([str(exe)]) == 0
+
+
+def test_load_cloud_kitti_bin_and_ply(tmp_path, lib):
+    """file_utils.cpp:20-141: KITTI .bin, ASCII PLY, binary PLY with extra properties, CRLF
+    header.  Host-side only: runs without a GPU."""
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-50, 50, (1234, 3)).astype(np.float32)
+    inten = rng.uniform(0, 1, (1234, 1)).astype(np.float32)
+    kitti = tmp_path / "000000.bin"
+    np.hstack([pts, inten]).tofile(kitti)
+    got = capi.load_cloud(str(kitti))
+    assert got.dtype == np.float64 and (got == pts.astype(np.float64)).all()
+
+    ascii_ply = tmp_path / "a.ply"
+    with open(ascii_ply, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 5\nproperty float x\nproperty float y\n"
+                "property float z\nproperty float intensity\nend_header\n")
+        for p in pts[:5]:
+            f.write("%r %r %r 0.5\n" % (float(p[0]), float(p[1]), float(p[2])))
+    assert (capi.load_cloud(str(ascii_ply)) == pts[:5].astype(np.float64)).all()
+
+    bin_ply = tmp_path / "b.ply"
+    with open(bin_ply, "wb") as f:     # intensity FIRST and a uchar in between: offsets matter; CRLF header
+        f.write(b"ply\r\nformat binary_little_endian 1.0\r\nelement vertex 1234\r\nproperty float intensity\r\n"
+                b"property float x\r\nproperty uchar ring\r\nproperty float y\r\nproperty float z\r\nend_header\n")
+        rec = np.zeros(1234, dtype=[("i", "<f4"), ("x", "<f4"), ("r", "u1"), ("y", "<f4"), ("z", "<f4")])
+        rec["i"], rec["x"], rec["y"], rec["z"], rec["r"] = inten[:, 0], pts[:, 0], pts[:, 1], pts[:, 2], 7
+        f.write(rec.tobytes())
+    assert (capi.load_cloud(str(bin_ply)) == pts.astype(np.float64)).all()
+
+    with pytest.raises(capi.IcpError) as e:
+        capi.load_cloud(str(tmp_path / "missing.ply"))
+    assert e.value.code == capi.ERR_ARG and "Cannot open file" in str(e.value)
+    empty = tmp_path / "e.bin"
+    empty.write_bytes(b"")
+    assert capi.load_cloud(str(empty)).shape == (0, 3)
