@@ -82,10 +82,13 @@ __device__ inline void smallest_eigvec_sym3(const double c[6], double out[3])
 // 6x6 symmetric solve, Eigen-3.4 LDLT semantics: diagonal pivoting on the largest
 // |diagonal| (first maximum), unit-lower L, pseudo-inverse of D with |D_i| <= DBL_MIN
 // mapped to 0.  M is the full symmetric matrix (row-major 36), overwritten.
-__device__ inline void ldlt6_solve(double *M, const double *rhs, double *x)
+// `work` holds 12 doubles (pivot indices and a temporary row); like M it should live in LDS:
+// the pivot swaps index at run time, so private arrays would land in scratch (global memory).
+__device__ inline void ldlt6_solve(double *M, const double *rhs, double *x, double *work)
 {
-    int perm[6];
-    double w[6];
+    double *w = work;
+    double *permf = work + 6; // pivot row of step k, kept as a double
+#define perm(k) permf[k]
 #define A(i, j) M[(i) * 6 + (j)]
     for (int k = 0; k < 6; ++k) {
         int piv = k;
@@ -94,7 +97,7 @@ __device__ inline void ldlt6_solve(double *M, const double *rhs, double *x)
             const double v = fabs(A(i, i));
             if (v > best) { best = v; piv = i; }
         }
-        perm[k] = piv;
+        perm(k) = (double)piv;
         if (piv != k) {
             // symmetric row/column interchange carried out on the lower triangle
             for (int j = 0; j < k; ++j) { const double t = A(k, j); A(k, j) = A(piv, j); A(piv, j) = t; }
@@ -118,14 +121,14 @@ __device__ inline void ldlt6_solve(double *M, const double *rhs, double *x)
         const double d = A(k, k);
         const bool ok = fabs(d) > 0.0;
         if (k == 0 && !ok) {
-            for (int j = 0; j < 6; ++j) perm[j] = j;
+            for (int j = 0; j < 6; ++j) perm(j) = (double)j;
             break;
         }
         if (ok)
             for (int i = k + 1; i < 6; ++i) A(i, k) /= d;
     }
     for (int i = 0; i < 6; ++i) x[i] = rhs[i];
-    for (int k = 0; k < 6; ++k) { const double t = x[k]; x[k] = x[perm[k]]; x[perm[k]] = t; }
+    for (int k = 0; k < 6; ++k) { const int pk = (int)perm(k); const double t = x[k]; x[k] = x[pk]; x[pk] = t; }
     for (int i = 1; i < 6; ++i) {
         double s = 0.0;
         for (int j = 0; j < i; ++j) s += A(i, j) * x[j];
@@ -140,8 +143,9 @@ __device__ inline void ldlt6_solve(double *M, const double *rhs, double *x)
         for (int j = i + 1; j < 6; ++j) s += A(j, i) * x[j];
         x[i] -= s;
     }
-    for (int k = 5; k >= 0; --k) { const double t = x[k]; x[k] = x[perm[k]]; x[perm[k]] = t; }
+    for (int k = 5; k >= 0; --k) { const int pk = (int)perm(k); const double t = x[k]; x[k] = x[pk]; x[pk] = t; }
 #undef A
+#undef perm
 }
 
 // x = [rx ry rz tx ty tz] -> row-major 4x4 (icp.hpp:123-143)

@@ -216,7 +216,8 @@ __device__ inline void finish_sums(const double *__restrict__ partials, int nblo
 }
 
 // error, convergence tests, solve, accumulate (icp.hpp:206-231 / 251-255)
-__device__ inline void step_update(IcpState *st, double *history, int final_pass)
+// `work`: 64 doubles of LDS for the 6x6 solve (run-time pivot indexing: not private memory)
+__device__ inline void step_update(IcpState *st, double *history, int final_pass, double *work)
 {
     if (st->done) {
         if (final_pass) {
@@ -249,7 +250,7 @@ __device__ inline void step_update(IcpState *st, double *history, int final_pass
         st->done = 1;
         return;
     }
-    double M[36], rhs[6], x[6];
+    double *M = work, *rhs = work + 36, *x = work + 42;
     int o = 0;
     for (int r = 0; r < 6; ++r)
         for (int c = r; c < 6; ++c) {
@@ -258,7 +259,7 @@ __device__ inline void step_update(IcpState *st, double *history, int final_pass
             ++o;
         }
     for (int r = 0; r < 6; ++r) rhs[r] = st->sums[21 + r];
-    ldlt6_solve(M, rhs, x);              // icp.hpp:120
+    ldlt6_solve(M, rhs, x, work + 48);   // icp.hpp:120
     twist_to_transform(x, st->delta);    // icp.hpp:123-143
     mul44(st->delta, st->total, st->total); // icp.hpp:229
     st->prev_error = error;              // icp.hpp:231
@@ -278,10 +279,11 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step(const double *__
                                                      double *history, int final_pass, int *progress,
                                                      int ticket)
 {
+    __shared__ double work[64];
     if (!st->done) finish_sums(partials, nblocks, n_local, st);
     __syncthreads();
     if (threadIdx.x == 0) {
-        step_update(st, history, final_pass);
+        step_update(st, history, final_pass, work);
         publish_progress(progress, ticket, st);
     }
 }
@@ -300,8 +302,9 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(const double *__restr
 
 __global__ void k_step(IcpState *st, double *history, int final_pass, int *progress, int ticket)
 {
+    __shared__ double work[64];
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        step_update(st, history, final_pass);
+        step_update(st, history, final_pass, work);
         publish_progress(progress, ticket, st);
     }
 }
@@ -312,8 +315,9 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_solve(const double *_
 {
     finish_sums(partials, nblocks, n_local, st);
     __syncthreads();
+    __shared__ double work[64];
     if (threadIdx.x == 0) {
-        double M[36], rhs[6], x[6];
+        double *M = work, *rhs = work + 36, *x = work + 42;
         int o = 0;
         for (int r = 0; r < 6; ++r)
             for (int c = r; c < 6; ++c) {
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_solve(const double *_
                 ++o;
             }
         for (int r = 0; r < 6; ++r) rhs[r] = st->sums[21 + r];
-        ldlt6_solve(M, rhs, x);
+        ldlt6_solve(M, rhs, x, work + 48);
         twist_to_transform(x, st->delta);
     }
 }
