@@ -499,7 +499,6 @@ __device__ __forceinline__ void scan_range(const double *__restrict__ sorted,
 // of the slot: three coalesced streams), so 4 slots are in flight per wave and ~6 waves per
 // SIMD hide the latency.
 constexpr int kResolveQ = 16;
-constexpr int kResolveFlagSplits = 32; // splits per lane whose certificate flags fit the 64-bit mask (128 splits)
 
 __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ qry, int n,
                                                     const double *__restrict__ sorted,
@@ -525,7 +524,6 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
     // phase 1: smallest coarse value over the splits (each quarter takes every 4th split)
     float best = kBig;
     int bs = 0;
-#pragma unroll 8
     for (int s = quarter; s < splits; s += 4) {
         const float v = coarse[(size_t)s * n + ic].x;
         if (v < best) {
@@ -584,42 +582,17 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
         }
     }
 
-    // phase 3: certificate, split by split (tau depends on the split's frame).  First a pure
-    // load + arithmetic pass that only records flags (no cross-lane work inside: the loads of
-    // all splits are in flight together), two bits per split a lane looks at; then the rare
-    // flagged (query, split) pairs are scanned wave-cooperatively.
+    // phase 3: certificate, split by split (tau depends on the split's frame)
     const double sq = sqrt(bd);
     unsigned extra_slots = 0, extra_splits = 0;
-    unsigned long long flags = 0ull; // bit 2u: slot scan, bit 2u+1: whole split, u = (s - quarter) / 4
-    if (valid) {
-#pragma unroll 8
-        for (int u = 0; u < kResolveFlagSplits; ++u) {
-            const int s = quarter + 4 * u;
-            if (s < splits) {
-                const float2 v = coarse[(size_t)s * n + ic];
-                const float tauf = split_tau(px, py, pz, frames[s], bd, sq);
-                const bool whole = v.y <= tauf;                  // a second column is inside the bound
-                const bool slot = !whole && s != bs && v.x <= tauf;
-                flags |= (unsigned long long)((whole ? 2u : 0u) | (slot ? 1u : 0u)) << (2 * u);
-            }
-        }
-    }
-    for (int s0 = 0, u = 0; s0 < splits; s0 += 4, ++u) {
+    for (int s0 = 0; s0 < splits; s0 += 4) {
         const int s = s0 + quarter;
         bool whole = false, slot = false;
-        if (u < kResolveFlagSplits) {
-            if (!__ballot(flags != 0ull)) { // nothing left to do in the recorded range: skip ahead
-                s0 = 4 * kResolveFlagSplits - 4;
-                u = kResolveFlagSplits - 1;
-                continue;
-            }
-            whole = (flags >> (2 * u)) & 2ull;
-            slot = (flags >> (2 * u)) & 1ull;
-            flags &= ~(3ull << (2 * u));
-        } else if (s < splits && valid) { // more than 4 * kResolveFlagSplits splits: evaluate in place
-            const float2 v = coarse[(size_t)s * n + ic];
+        float2 v = make_float2(kBig, kBig);
+        if (s < splits && valid) {
+            v = coarse[(size_t)s * n + ic];
             const float tauf = split_tau(px, py, pz, frames[s], bd, sq);
-            whole = v.y <= tauf;
+            whole = v.y <= tauf;                       // a second column is inside the bound
             slot = !whole && s != bs && v.x <= tauf;
         }
         unsigned long long pend = __ballot(whole || slot);
@@ -628,9 +601,8 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
             pend &= pend - 1;
             const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
             const int w = __shfl((int)whole, L, 64);
+            const int c = __shfl((int)(__float_as_uint(v.x) & 31u), L, 64);
             const int sL = s0 + (L >> 4);
-            const int icL = __shfl(ic, L, 64);
-            const int c = (int)(__float_as_uint(coarse[(size_t)sL * n + icL].x) & 31u); // uniform reload of the tag
             double d = 1.7976931348623157e308;
             int j = 0x7fffffff;
             if (w) scan_range(sorted, perm, m, ms, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
