@@ -42,7 +42,10 @@ extern "C" {
 /* nearest-neighbour search engines (all return the exact fp64 nearest neighbour) */
 #define ICPMI_SEARCH_AUTO 0
 #define ICPMI_SEARCH_EXACT_F64 1     /* fp64 brute force, SGPR-broadcast targets */
-#define ICPMI_SEARCH_MFMA_BF16 2     /* bf16x3 MFMA coarse pass over all pairs + certified fp64 resolve */
+#define ICPMI_SEARCH_MFMA_BF16 2     /* bf16 MFMA coarse pass over ALL pairs + certified fp64 resolve */
+#define ICPMI_SEARCH_MFMA_PRUNED 3   /* the same, skipping (query block, target split) pairs whose bounding
+                                        boxes are farther apart than the block's known neighbour distance;
+                                        same exact result, not an all-pairs pass (icpmi_align* only) */
 
 typedef struct icpmi_ctx icpmi_ctx;
 
@@ -88,6 +91,8 @@ typedef struct {
     int64_t nn_recheck_queries;                      /* extra 128-target slots scanned in fp64 (MFMA engine) */
     int64_t nn_fallback_queries;                     /* whole 2048-target splits re-scanned in fp64 */
     int64_t knn_fallback_rows;                       /* normal-estimation rows resolved by the exact k-NN kernel */
+    int64_t nn_coarse_blocks;                        /* (512-query block, 2048-target split) workgroups launched */
+    int64_t nn_pruned_blocks;                        /* of those, skipped by ICPMI_SEARCH_MFMA_PRUNED's box test */
 } icpmi_profile;
 
 void icpmi_options_default(icpmi_options *opt);

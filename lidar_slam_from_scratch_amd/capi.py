@@ -13,7 +13,7 @@ from . import build as _build
 OK = 0
 ERR_NULL, ERR_EMPTY_SOURCE, ERR_EMPTY_TARGET, ERR_CAPACITY = -1, -2, -3, -4
 ERR_HIP, ERR_RCCL, ERR_ARG, ERR_NO_DEVICE = -5, -6, -7, -8
-SEARCH_AUTO, SEARCH_EXACT_F64, SEARCH_MFMA_BF16 = 0, 1, 2
+SEARCH_AUTO, SEARCH_EXACT_F64, SEARCH_MFMA_BF16, SEARCH_MFMA_PRUNED = 0, 1, 2, 3
 UNIQUE_ID_BYTES = 128
 
 EXPORTS = [
@@ -53,7 +53,8 @@ class Profile(C.Structure):
                 ("total_ms", C.c_double), ("calls", C.c_int64), ("loop_ms", C.c_double),
                 ("setup_ms", C.c_double),
                 ("nn_pairs", C.c_double), ("nn_recheck_queries", C.c_int64),
-                ("nn_fallback_queries", C.c_int64), ("knn_fallback_rows", C.c_int64)]
+                ("nn_fallback_queries", C.c_int64), ("knn_fallback_rows", C.c_int64),
+                ("nn_coarse_blocks", C.c_int64), ("nn_pruned_blocks", C.c_int64)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)

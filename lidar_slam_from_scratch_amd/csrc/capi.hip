@@ -82,6 +82,8 @@ struct icpmi_ctx {
     DevBuf vox_keys, vox_vals, vox_out;             // voxel filter: 64-bit keys (in/out/unique), values + run data, result
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
+    DevBuf src_sort, bounds;                  // pruned engine: Morton order of the source, per-block bounds
+    bool nn_pruned = false;                   // ICPMI_SEARCH_MFMA_PRUNED requested (align calls only)
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
     int nn_splits = 0;
     int nn_ms = 0;                            // component stride of the SoA sorted target
@@ -186,10 +188,11 @@ struct StageTimer {
 void harvest_profile(icpmi_ctx *ctx)
 {
     if (ctx->opt.profile && ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && ctx->nn_misc.p) {
-        unsigned long long cnt[2] = {0, 0};
+        unsigned long long cnt[3] = {0, 0, 0};
         if (hipMemcpy(cnt, (char *)ctx->nn_misc.p + 128, sizeof(cnt), hipMemcpyDeviceToHost) == hipSuccess) {
             ctx->prof.nn_recheck_queries += (int64_t)cnt[0];
             ctx->prof.nn_fallback_queries += (int64_t)cnt[1];
+            ctx->prof.nn_pruned_blocks += (int64_t)cnt[2];
             (void)hipMemset((char *)ctx->nn_misc.p + 128, 0, sizeof(cnt));
         }
     }
@@ -222,6 +225,10 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     int engine = ctx->opt.search;
     if (engine == ICPMI_SEARCH_AUTO)
         engine = (m >= 4 * kSplitTargets && n_hint >= 1024) ? ICPMI_SEARCH_MFMA_BF16 : ICPMI_SEARCH_EXACT_F64;
+    // the pruned engine is the MFMA engine plus block/split culling inside the ICP loop; the
+    // stand-alone searches (nearest_batch, normals) have no previous neighbour to bound with
+    ctx->nn_pruned = engine == ICPMI_SEARCH_MFMA_PRUNED;
+    if (ctx->nn_pruned) engine = ICPMI_SEARCH_MFMA_BF16;
     ctx->nn_engine = engine;
     if (engine != ICPMI_SEARCH_MFMA_BF16) return ICPMI_OK;
     const int splits = (m + kSplitTargets - 1) / kSplitTargets;
@@ -256,7 +263,7 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     hipLaunchKernelGGL(k_pack_targets, dim3((splits * kSplitTiles * 64 + 255) / 256), dim3(256), 0, s,
                        (const double *)ctx->tgt_sorted.p, m, ms, (const SplitFrame *)ctx->frames.p,
                        (uint4 *)ctx->bpack.p, splits);
-    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->nn_misc.p + 128, 0, 16, s));
+    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->nn_misc.p + 128, 0, 24, s));
     HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;
 }
@@ -267,7 +274,7 @@ int resolve_blocks(int n) { return (n + 4 * kResolveQ - 1) / (4 * kResolveQ); }
 
 int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx, double *d_d2,
                    const IcpState *st, const double *d_tgt = nullptr, const double *d_nrm = nullptr,
-                   double *d_partials = nullptr)
+                   double *d_partials = nullptr, const BlockBounds *bounds = nullptr)
 {
     const int splits = ctx->nn_splits;
     int rc;
@@ -280,7 +287,8 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
         StageTimer tc(ctx, ST_COARSE); // the dominant kernel alone (matches rocprofv3's per-kernel average)
         hipLaunchKernelGGL((k_nn_coarse<0, kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
                            dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,
-                           (float2 *)ctx->coarse.p, (float *)nullptr, st);
+                           (float2 *)ctx->coarse.p, (float *)nullptr, bounds, counters + 2, st);
+        ctx->prof.nn_coarse_blocks += (int64_t)((n + kCoarseQueries - 1) / kCoarseQueries) * splits;
     }
     hipLaunchKernelGGL(k_nn_resolve, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream,
                        d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits,
@@ -352,7 +360,8 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
             const int nq = (int)std::min<long>(chunk, row1 - c0);
             hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves>), dim3((nq + kCoarseQueries - 1) / kCoarseQueries, splits),
                                dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
-                               frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
+                               frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const BlockBounds *)nullptr,
+                               (unsigned long long *)nullptr, (const IcpState *)nullptr);
             hipLaunchKernelGGL(k_knn_resolve, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq,
                                (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots,
                                frames, knn, fb_list, fb_count);
@@ -507,17 +516,50 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, 0, m, nrm))) return rc;
     }
 
+    // Pruned engine: the source is put in Morton order once (a rigid motion keeps neighbours
+    // together), so that every block of kCoarseQueries consecutive rows of `cur` is a compact
+    // blob whose bounding box can rule whole target splits out.  The order of the rows of
+    // `cur` is internal: only sums over all rows leave this function.
+    const bool pruned = fused && ctx->nn_pruned;
+    const int qblocks = (n + kCoarseQueries - 1) / kCoarseQueries;
+    BlockBounds *bounds = nullptr;
+    const unsigned *src_perm = nullptr;
+    if (pruned) {
+        size_t sort_bytes = 0;
+        HIP_TRY(ctx, sort_pairs_u32(nullptr, &sort_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned)n, s));
+        const int bblocks = std::max(1, std::min(256, (n + 255) / 256));
+        if ((rc = reserve(ctx, ctx->src_sort, sizeof(unsigned) * 4 * (size_t)n))) return rc;
+        if ((rc = reserve(ctx, ctx->sort_tmp, sort_bytes))) return rc; // the target's sort is done (stream order)
+        if ((rc = reserve(ctx, ctx->bbox_part, sizeof(double) * 6 * (size_t)bblocks))) return rc;
+        if ((rc = reserve(ctx, ctx->bounds, sizeof(BlockBounds) * (size_t)qblocks))) return rc;
+        bounds = (BlockBounds *)ctx->bounds.p;
+        NnFrame *sframe = (NnFrame *)((char *)ctx->nn_misc.p + 64);
+        unsigned *keys_in = (unsigned *)ctx->src_sort.p, *keys_out = keys_in + n, *vals_in = keys_in + 2 * (size_t)n,
+                 *perm = keys_in + 3 * (size_t)n;
+        StageTimer t(ctx, ST_SETUP);
+        hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_src, n, (double *)ctx->bbox_part.p);
+        hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, sframe);
+        hipLaunchKernelGGL(k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, (const NnFrame *)sframe,
+                           keys_in, vals_in);
+        HIP_TRY(ctx, sort_pairs_u32(ctx->sort_tmp.p, &sort_bytes, keys_in, keys_out, vals_in, perm, (unsigned)n, s));
+        src_perm = perm;
+    }
+
     // current_source = source * R0^T + t0^T (icp.hpp:174-176)
     {
         StageTimer t(ctx, ST_TRANSFORM);
-        hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, d_src,
-                           cur, n, ctx->d_state, 1, 0);
+        if (pruned)
+            hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, d_src, src_perm, cur, n,
+                               (const IcpState *)ctx->d_state, 1, 0, d_tgt, (const int *)nullptr, m, bounds);
+        else
+            hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, d_src,
+                               cur, n, ctx->d_state, 1, 0);
     }
 
     auto iteration = [&](int final_pass, int *progress, int ticket) -> int {
         int r2;
         if (fused) {
-            if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, ctx->d_state, d_tgt, nrm, partials))) return r2;
+            if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, ctx->d_state, d_tgt, nrm, partials, bounds))) return r2;
         } else {
             if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, ctx->d_state))) return r2;
         }
@@ -538,8 +580,13 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         }
         if (!final_pass) {
             StageTimer t(ctx, ST_TRANSFORM);
-            hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
-                               cur, cur, n, ctx->d_state, 0, 1);
+            if (pruned) // + each block's box and its exact distance bound to this iteration's neighbours
+                hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, (const double *)cur,
+                                   (const unsigned *)nullptr, cur, n, (const IcpState *)ctx->d_state, 0, 1, d_tgt,
+                                   (const int *)idx, m, bounds);
+            else
+                hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
+                                   cur, cur, n, ctx->d_state, 0, 1);
         }
         return ICPMI_OK;
     };
@@ -706,6 +753,8 @@ int icpmi_create(const icpmi_options *opt, icpmi_ctx **out)
     else icpmi_options_default(&o);
     if (o.normal_k < 1 || o.normal_k > 64)
         return fail(nullptr, ICPMI_ERR_ARG, "normal_k %d outside [1,64]", o.normal_k);
+    if (o.search < ICPMI_SEARCH_AUTO || o.search > ICPMI_SEARCH_MFMA_PRUNED)
+        return fail(nullptr, ICPMI_ERR_ARG, "search %d is not an ICPMI_SEARCH_* value", o.search);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return fail(nullptr, ICPMI_ERR_NO_DEVICE, "no HIP device visible");
@@ -744,7 +793,7 @@ void icpmi_destroy(icpmi_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
     for (DevBuf *b : {&ctx->cur, &ctx->nrm, &ctx->idx, &ctx->part_d2, &ctx->part_idx, &ctx->partials,
-                      &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out,
+                      &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out, &ctx->src_sort, &ctx->bounds,
                       &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin,
                       &ctx->fb_list, &ctx->sort_keys, &ctx->sort_tmp, &ctx->tgt_sorted, &ctx->frames, &ctx->vox_keys,
                       &ctx->vox_vals, &ctx->vox_out})

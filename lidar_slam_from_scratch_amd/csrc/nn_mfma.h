@@ -84,6 +84,14 @@ struct NnFrame {     // bounding box of the whole target (Morton quantisation)
 struct SplitFrame {  // per split of 2048 sorted targets
     double c[3];     // centre the split's operands are expressed about
     double rho;      // >= max |q - c| over the split (inflated)
+    double lo[3], hi[3]; // exact bounding box of the split's targets
+};
+// Per block of kCoarseQueries consecutive queries (pruned engine): bounding box of the block
+// and an upper bound of every member's nearest-neighbour squared distance.
+struct BlockBounds {
+    double lo[3], hi[3];
+    double ub;       // max over the block of |query - its previous nearest target|^2 (inf: unknown)
+    double pad;
 };
 
 // ---- bounding box -----------------------------------------------------------------------------
@@ -218,6 +226,8 @@ __global__ __launch_bounds__(256) void k_split_frames(const double *__restrict__
                 h = red[w][3 + a] > h ? red[w][3 + a] : h;
             }
             frames[s].c[a] = 0.5 * (l + h);
+            frames[s].lo[a] = l;
+            frames[s].hi[a] = h;
             const double half = 0.5 * (h - l);
             h2 += half * half;
         }
@@ -308,7 +318,8 @@ template <int MODE, int QT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     const double *__restrict__ qry, int n, const uint4 *__restrict__ Bpack,
     const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/,
-    float *__restrict__ slotmin /*[n][splits*32]*/, const IcpState *__restrict__ st)
+    float *__restrict__ slotmin /*[n][splits*32]*/, const BlockBounds *__restrict__ bounds,
+    unsigned long long *__restrict__ pruned_count, const IcpState *__restrict__ st)
 {
     static_assert(QT % 2 == 0, "operands are staged 64 queries at a time");
     constexpr int THREADS = 64 * WAVES;
@@ -319,6 +330,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     __shared__ uint4 lds[SCRATCH16];
     const int s = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (bounds) {
+        // Pruned engine.  Every query of this block already has a target within sqrt(ub)
+        // (its previous neighbour, re-measured exactly after the pose update), and no target
+        // of this split is closer to any of them than the gap between the two bounding
+        // boxes: if gap^2 > ub, strictly, the split cannot hold a nearest neighbour (nor an
+        // equal-distance one), so the whole workgroup only writes "no candidate".
+        const BlockBounds &bb = bounds[blockIdx.x];
+        const SplitFrame &sf = frames[s];
+        double g2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double g1 = bb.lo[a] - sf.hi[a], g3 = sf.lo[a] - bb.hi[a];
+            const double g = g1 > g3 ? g1 : g3;
+            g2 += g > 0.0 ? g * g : 0.0;
+        }
+        if (g2 * (1.0 - 1e-12) > bb.ub * (1.0 + 1e-12)) {
+            const int iq = blockIdx.x * (kTile * QT * WAVES) + threadIdx.x;
+            if (MODE == 0 && iq < n) coarse[(size_t)s * n + iq] = make_float2(kBig, kBig);
+            if (threadIdx.x == 0 && pruned_count) atomicAdd(pruned_count, 1ull);
+            return; // workgroup-uniform
+        }
+    }
     const int q0 = (blockIdx.x * WAVES + wave) * (kTile * QT);
     const double c0 = frames[s].c[0], c1 = frames[s].c[1], c2 = frames[s].c[2];
 
@@ -436,6 +469,78 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
             v2 = min3f(hi, v2, o2);
             if (half == 0 && iq < n) coarse[(size_t)s * n + iq] = make_float2(v1, v2);
         }
+    }
+}
+
+// ---- pose update + block bounds (pruned engine) ---------------------------------------------------
+// out[i] = T * in[src(i)] like k_transform (icp.hpp:174-176,225-226), src(i) = perm[i] when a
+// permutation is given (Morton order of the source, applied once with the initial transform);
+// the same pass measures, exactly, the distance from the moved point to its previous nearest
+// target and reduces the block's bounding box and the maximum of those distances.
+__global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
+    const double *in, const unsigned *__restrict__ perm, double *out, int n,
+    const IcpState *__restrict__ st, int which, int honour_done, const double *__restrict__ tgt,
+    const int *__restrict__ prev_idx, int m, BlockBounds *__restrict__ bounds)
+{
+    static_assert(kCoarseQueries == 512, "one block of this kernel == one query block of k_nn_coarse");
+    if (honour_done && st->done) return;
+    const double *T = which ? st->total : st->delta;
+    const int i = blockIdx.x * kCoarseQueries + threadIdx.x;
+    double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308}, ub = 0.0;
+    if (i < n) {
+        const size_t si = perm ? perm[i] : (unsigned)i;
+        const double x = in[3 * si], y = in[3 * si + 1], z = in[3 * si + 2];
+        double p[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) p[r] = ((x * T[4 * r] + y * T[4 * r + 1]) + z * T[4 * r + 2]) + T[4 * r + 3];
+        out[3 * i] = p[0];
+        out[3 * i + 1] = p[1];
+        out[3 * i + 2] = p[2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) lo[a] = hi[a] = p[a];
+        ub = __builtin_inf();
+        if (prev_idx) {
+            const int j = prev_idx[i];
+            if ((unsigned)j < (unsigned)m) ub = sqdist(tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2], p[0], p[1], p[2]);
+        }
+    }
+    __shared__ double red[8][7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double l2 = __shfl_xor(lo[a], off, 64), h2 = __shfl_xor(hi[a], off, 64);
+            lo[a] = l2 < lo[a] ? l2 : lo[a];
+            hi[a] = h2 > hi[a] ? h2 : hi[a];
+        }
+        const double u2 = __shfl_xor(ub, off, 64);
+        ub = u2 > ub ? u2 : ub;
+    }
+    if (lane == 0) {
+        for (int a = 0; a < 3; ++a) {
+            red[wave][a] = lo[a];
+            red[wave][3 + a] = hi[a];
+        }
+        red[wave][6] = ub;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        BlockBounds b;
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = red[0][a];
+            b.hi[a] = red[0][3 + a];
+        }
+        b.ub = red[0][6];
+        for (int w = 1; w < 8; ++w) {
+            for (int a = 0; a < 3; ++a) {
+                b.lo[a] = red[w][a] < b.lo[a] ? red[w][a] : b.lo[a];
+                b.hi[a] = red[w][3 + a] > b.hi[a] ? red[w][3 + a] : b.hi[a];
+            }
+            b.ub = red[w][6] > b.ub ? red[w][6] : b.ub;
+        }
+        b.pad = 0.0;
+        bounds[blockIdx.x] = b;
     }
 }
 

@@ -24,14 +24,15 @@ def oracle():
     return orc
 
 
-@pytest.fixture(scope="session", params=["exact_f64", "mfma_bf16"])
+@pytest.fixture(scope="session", params=["exact_f64", "mfma_bf16", "mfma_pruned"])
 def gpu_ctx(request):
     """One context per search engine for the whole GPU session; every parity test runs
     against both (they must return identical indices).  Fails loudly (no skip, no
     fallback) when the HIP library or the device is missing."""
     from lidar_slam_from_scratch_amd import build, capi
     build.build_library()
-    search = {"exact_f64": capi.SEARCH_EXACT_F64, "mfma_bf16": capi.SEARCH_MFMA_BF16}[request.param]
+    search = {"exact_f64": capi.SEARCH_EXACT_F64, "mfma_bf16": capi.SEARCH_MFMA_BF16,
+              "mfma_pruned": capi.SEARCH_MFMA_PRUNED}[request.param]
     ctx = capi.Context(device=0, search=search, profile=2)
     ctx.engine = request.param
     yield ctx

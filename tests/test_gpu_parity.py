@@ -455,7 +455,7 @@ def test_mfma_engine_certificate_paths(gpu_ctx, oracle):
     idx, d2 = gpu_ctx.nearest_batch(tgt, qry)
     oidx, od2 = oracle.nearest_batch_brute(tgt, qry)
     assert (idx == oidx).all() and (d2 == od2).all()
-    if gpu_ctx.engine == "mfma_bf16":
+    if gpu_ctx.engine.startswith("mfma"):
         gpu_ctx.reset_profile()
         gpu_ctx.nearest_batch(tgt, qry)
         p = gpu_ctx.get_profile()
@@ -532,3 +532,45 @@ def test_profile_counters(gpu_ctx):
     assert p["nn_launches"] == 6 and p["reduce_launches"] == 6 and p["normals_launches"] == 1
     assert p["nn_ms"] > 0 and p["total_ms"] >= p["loop_ms"] > 0
     assert p["nn_pairs"] == 6 * 2000 * 2000
+
+
+@pytest.mark.parametrize("case", ["c3_small_20k", "lidar_pair", "far_start"])
+def test_pruned_engine_skips_blocks_and_keeps_the_result(case, oracle):
+    """ICPMI_SEARCH_MFMA_PRUNED culls (query block, target split) pairs with a bounding-box
+    test against each block's exact distance to its previous neighbours.  The cull is
+    conservative, so the correspondences -- hence error history, iteration count and pose
+    -- are those of the all-pairs engine (sums are formed in Morton order of the source, so
+    the last bits of the history may differ)."""
+    if case == "c3_small_20k":
+        src, tgt, _ = synth.c3_uniform(20000, seed=14, perm_seed=15)
+        kw = dict(max_iterations=30, tolerance=0.0, min_error=0.0)
+    elif case == "lidar_pair":
+        src, tgt, _ = synth.c2_lidar_pair()
+        kw = dict(max_iterations=50, tolerance=1e-6, min_error=1e-9)
+    else:  # a start so far off that the first bounds prune nothing and most blocks miss the target box
+        src, tgt, _ = synth.c3_uniform(12000, seed=3, perm_seed=4)
+        kw = dict(max_iterations=8, tolerance=0.0, min_error=0.0,
+                  initial_transform=synth.make_transform((0.3, -0.2, 0.4), (35.0, -20.0, 6.0)))
+    cfg = capi.Context.make_config(**kw)
+    full = capi.Context(device=0, search=capi.SEARCH_MFMA_BF16, profile=2)
+    pruned = capi.Context(device=0, search=capi.SEARCH_MFMA_PRUNED, profile=2)
+    try:
+        a, ha = full.align(src, tgt, cfg)
+        b, hb = pruned.align(src, tgt, cfg)
+        p = pruned.get_profile()
+        q = full.get_profile()
+    finally:
+        full.close()
+        pruned.close()
+    assert q["nn_pruned_blocks"] == 0 and q["nn_coarse_blocks"] > 0
+    assert p["nn_coarse_blocks"] == q["nn_coarse_blocks"]
+    if case == "c3_small_20k":
+        assert p["nn_pruned_blocks"] > 0.3 * p["nn_coarse_blocks"], p
+    elif case == "lidar_pair":   # ~3000-point frames: few, large blocks -- some culling only
+        assert p["nn_pruned_blocks"] > 0, p
+    assert a.num_iterations == b.num_iterations and bool(a.converged) == bool(b.converged)
+    np.testing.assert_allclose(hb, ha, rtol=1e-12, atol=1e-15)
+    dt, dr = synth.pose_delta(T_of(a), T_of(b))
+    assert dt < 1e-10 and dr < 1e-10
+    ref = oracle.icp_point_to_plane(src, tgt, **kw)
+    check_against(b, hb, ref.transformation, ref.converged, ref.num_iterations, ref.error_history)
