@@ -67,7 +67,11 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000)
-    ap.add_argument("--search", type=int, default=0, help="0 auto, 1 exact fp64, 2 mfma fp32 + recheck")
+    ap.add_argument("--search", type=int, default=0,
+                    help="0 auto (= 2 at this size), 1 exact fp64, 2 bf16 MFMA over all pairs + certified resolve, "
+                         "3 the same with box culling of (query block, target split) units")
+    ap.add_argument("--no-pruned-extra", action="store_true",
+                    help="skip the extra, untimed-by-the-contract run of the opt-in pruned engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=None)
     args = ap.parse_args()
@@ -133,6 +137,37 @@ def main():
     call(args.steps)
     stage = ctx.get_profile()
 
+    # extra: the opt-in pruned engine (ICPMI_SEARCH_MFMA_PRUNED) on the same job, same timing
+    # protocol.  Reported beside `value`, never as `value`: it is not an all-pairs pass.
+    pruned = None
+    if not args.no_pruned_extra and args.search in (0, 2):
+        ctx.close()
+        ctx = capi.Context(device=local_rank, search=capi.SEARCH_MFMA_PRUNED, profile=1)
+        if world > 1:
+            icpdist.init_rccl(ctx, dist, device=dev)
+        if args.warmup > 0:
+            call(args.warmup)
+        ctx.reset_profile()
+        fence()
+        t0 = time.perf_counter()
+        pres, phist = call(args.steps)
+        fence()
+        pel = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([pel], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pel = float(t.item())
+        pp = ctx.get_profile()
+        pruned = {"value": args.steps / pel, "unit": "ICP iterations/s", "ms_per_step": 1e3 * pel / args.steps,
+                  "steady_state_it_per_s": (args.steps + 1) / (pp["loop_ms"] * 1e-3) if pp["loop_ms"] > 0 else None,
+                  "units_culled_frac": pp["nn_pruned_blocks"] / max(1, pp["nn_coarse_blocks"]),
+                  "coarse_avg_launch_ms": pp["coarse_ms"] / max(1, pp["coarse_launches"]),
+                  "pose_delta_vs_all_pairs": list(synth.pose_delta(np.array(pres.transformation[:]).reshape(4, 4),
+                                                                   np.array(res.transformation[:]).reshape(4, 4))),
+                  "history_max_abs_diff": float(np.abs(np.asarray(phist) - np.asarray(hist)).max()),
+                  "note": "opt-in ICPMI_SEARCH_MFMA_PRUNED: same correspondences, (512-query block, 2048-target "
+                          "split) units culled by a bounding-box test against the previous iteration's distances"}
+
     if rank == 0:
         n_local, m = hi - lo, tgt.shape[0]
         mfma = prof["coarse_launches"] > 0
@@ -173,6 +208,7 @@ def main():
                                                             "normals_ms", "setup_ms", "loop_ms", "total_ms")},
             "resolve_counters": {k: stage[k] for k in ("nn_recheck_queries", "nn_fallback_queries", "knn_fallback_rows")},
             "final_error": res.final_error,
+            "pruned_engine_extra": pruned,
             "roofline": {
                 "kernel": "k_nn_coarse (bf16 MFMA, all %dx%d pairs)" % (n_local, m) if mfma else "k_nn_f64",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -82,7 +82,7 @@ struct icpmi_ctx {
     DevBuf vox_keys, vox_vals, vox_out;             // voxel filter: 64-bit keys (in/out/unique), values + run data, result
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
-    DevBuf src_sort, bounds;                  // pruned engine: Morton order of the source, per-block bounds
+    DevBuf src_sort, blk_lists, work;         // pruned engine: Morton order of the source, per-block split lists, unit list
     bool nn_pruned = false;                   // ICPMI_SEARCH_MFMA_PRUNED requested (align calls only)
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
     int nn_splits = 0;
@@ -274,7 +274,7 @@ int resolve_blocks(int n) { return (n + 4 * kResolveQ - 1) / (4 * kResolveQ); }
 
 int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx, double *d_d2,
                    const IcpState *st, const double *d_tgt = nullptr, const double *d_nrm = nullptr,
-                   double *d_partials = nullptr, const BlockBounds *bounds = nullptr)
+                   double *d_partials = nullptr, int pruned_pass = -1)
 {
     const int splits = ctx->nn_splits;
     int rc;
@@ -285,14 +285,26 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     StageTimer t(ctx, ST_NN);
     {
         StageTimer tc(ctx, ST_COARSE); // the dominant kernel alone (matches rocprofv3's per-kernel average)
-        hipLaunchKernelGGL((k_nn_coarse<0, kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
-                           dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,
-                           (float2 *)ctx->coarse.p, (float *)nullptr, bounds, counters + 2, st);
+        if (pruned_pass >= 0) {
+            // pass p consumes the list counted in work_cnt[p & 1] and clears the other counter
+            unsigned *cnt = (unsigned *)((char *)ctx->nn_misc.p + 160);
+            hipLaunchKernelGGL((k_nn_coarse_list<kCoarseQT, kCoarseWaves>), dim3(2 * ctx->cu_count), dim3(kCoarseThreads), 0,
+                               ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames, (float2 *)ctx->coarse.p, splits,
+                               (const unsigned *)ctx->work.p, (const unsigned *)(cnt + (pruned_pass & 1)),
+                               cnt + ((pruned_pass + 1) & 1),
+                               (unsigned)(((n + kCoarseQueries - 1) / kCoarseQueries) * splits), counters + 2, st);
+        } else {
+            hipLaunchKernelGGL((k_nn_coarse<0, kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
+                               dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,
+                               (float2 *)ctx->coarse.p, (float *)nullptr, st);
+        }
         ctx->prof.nn_coarse_blocks += (int64_t)((n + kCoarseQueries - 1) / kCoarseQueries) * splits;
     }
+    const int *blk_cnt = pruned_pass >= 0 ? (const int *)ctx->blk_lists.p : nullptr;
+    const int *blk_list = blk_cnt ? blk_cnt + (n + kCoarseQueries - 1) / kCoarseQueries : nullptr;
     hipLaunchKernelGGL(k_nn_resolve, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream,
                        d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits,
-                       frames, d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, st);
+                       frames, d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, blk_cnt, blk_list, st);
     ctx->prof.nn_pairs += (double)n * (double)m;
     HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;
@@ -360,8 +372,7 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
             const int nq = (int)std::min<long>(chunk, row1 - c0);
             hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves>), dim3((nq + kCoarseQueries - 1) / kCoarseQueries, splits),
                                dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
-                               frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const BlockBounds *)nullptr,
-                               (unsigned long long *)nullptr, (const IcpState *)nullptr);
+                               frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
             hipLaunchKernelGGL(k_knn_resolve, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq,
                                (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots,
                                frames, knn, fb_list, fb_count);
@@ -522,7 +533,11 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // `cur` is internal: only sums over all rows leave this function.
     const bool pruned = fused && ctx->nn_pruned;
     const int qblocks = (n + kCoarseQueries - 1) / kCoarseQueries;
-    BlockBounds *bounds = nullptr;
+    int *blk_cnt = nullptr, *blk_list = nullptr;
+    unsigned *work = nullptr, *work_cnt = nullptr;
+    const SplitFrame *frames = (const SplitFrame *)ctx->frames.p;
+    const int splits = ctx->nn_splits;
+    int pass_no = 0; // coarse passes queued so far: selects the work counter (see k_nn_coarse_list)
     const unsigned *src_perm = nullptr;
     if (pruned) {
         size_t sort_bytes = 0;
@@ -531,8 +546,13 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         if ((rc = reserve(ctx, ctx->src_sort, sizeof(unsigned) * 4 * (size_t)n))) return rc;
         if ((rc = reserve(ctx, ctx->sort_tmp, sort_bytes))) return rc; // the target's sort is done (stream order)
         if ((rc = reserve(ctx, ctx->bbox_part, sizeof(double) * 6 * (size_t)bblocks))) return rc;
-        if ((rc = reserve(ctx, ctx->bounds, sizeof(BlockBounds) * (size_t)qblocks))) return rc;
-        bounds = (BlockBounds *)ctx->bounds.p;
+        if ((rc = reserve(ctx, ctx->blk_lists, sizeof(int) * (size_t)qblocks * ((size_t)splits + 1)))) return rc;
+        if ((rc = reserve(ctx, ctx->work, sizeof(unsigned) * (size_t)qblocks * (size_t)splits))) return rc;
+        blk_cnt = (int *)ctx->blk_lists.p;
+        blk_list = blk_cnt + qblocks;
+        work = (unsigned *)ctx->work.p;
+        work_cnt = (unsigned *)((char *)ctx->nn_misc.p + 160);
+        HIP_TRY(ctx, hipMemsetAsync(work_cnt, 0, 2 * sizeof(unsigned), s));
         NnFrame *sframe = (NnFrame *)((char *)ctx->nn_misc.p + 64);
         unsigned *keys_in = (unsigned *)ctx->src_sort.p, *keys_out = keys_in + n, *vals_in = keys_in + 2 * (size_t)n,
                  *perm = keys_in + 3 * (size_t)n;
@@ -550,7 +570,8 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         StageTimer t(ctx, ST_TRANSFORM);
         if (pruned)
             hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, d_src, src_perm, cur, n,
-                               (const IcpState *)ctx->d_state, 1, 0, d_tgt, (const int *)nullptr, m, bounds);
+                               (const IcpState *)ctx->d_state, 1, 0, d_tgt, (const int *)nullptr, m, frames, splits,
+                               blk_cnt, blk_list, work, work_cnt /* pass 0 reads counter 0 */);
         else
             hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, d_src,
                                cur, n, ctx->d_state, 1, 0);
@@ -559,7 +580,9 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     auto iteration = [&](int final_pass, int *progress, int ticket) -> int {
         int r2;
         if (fused) {
-            if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, ctx->d_state, d_tgt, nrm, partials, bounds))) return r2;
+            if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, ctx->d_state, d_tgt, nrm, partials,
+                                     pruned ? pass_no : -1))) return r2;
+            ++pass_no;
         } else {
             if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, ctx->d_state))) return r2;
         }
@@ -583,7 +606,8 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
             if (pruned) // + each block's box and its exact distance bound to this iteration's neighbours
                 hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, (const double *)cur,
                                    (const unsigned *)nullptr, cur, n, (const IcpState *)ctx->d_state, 0, 1, d_tgt,
-                                   (const int *)idx, m, bounds);
+                                   (const int *)idx, m, frames, splits, blk_cnt, blk_list, work,
+                                   work_cnt + (pass_no & 1) /* the next pass's counter */);
             else
                 hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
                                    cur, cur, n, ctx->d_state, 0, 1);
@@ -793,7 +817,7 @@ void icpmi_destroy(icpmi_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
     for (DevBuf *b : {&ctx->cur, &ctx->nrm, &ctx->idx, &ctx->part_d2, &ctx->part_idx, &ctx->partials,
-                      &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out, &ctx->src_sort, &ctx->bounds,
+                      &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out, &ctx->src_sort, &ctx->blk_lists, &ctx->work,
                       &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin,
                       &ctx->fb_list, &ctx->sort_keys, &ctx->sort_tmp, &ctx->tgt_sorted, &ctx->frames, &ctx->vox_keys,
                       &ctx->vox_vals, &ctx->vox_out})

@@ -314,45 +314,18 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
 // QT = 32-query tiles per wave (even); WAVES = waves per workgroup.  (Tried and dropped, see
 // scripts/micro/README.md: issuing a tile's min3 one tile behind its MFMAs, keeping the next B chunk
 // in flight in registers, QT = 4: none beat this form, all cost occupancy.)
+// One (query block, split) unit of the coarse pass: 512 queries against 2048 targets.
 template <int MODE, int QT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
-    const double *__restrict__ qry, int n, const uint4 *__restrict__ Bpack,
-    const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/,
-    float *__restrict__ slotmin /*[n][splits*32]*/, const BlockBounds *__restrict__ bounds,
-    unsigned long long *__restrict__ pruned_count, const IcpState *__restrict__ st)
+__device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int s, const int nsplits,
+                                            const double *__restrict__ qry, const int n,
+                                            const uint4 *__restrict__ Bpack,
+                                            const SplitFrame *__restrict__ frames,
+                                            float2 *__restrict__ coarse, float *__restrict__ slotmin)
 {
-    static_assert(QT % 2 == 0, "operands are staged 64 queries at a time");
     constexpr int THREADS = 64 * WAVES;
     constexpr int CHUNK16 = kChunkTiles * 64;  // uint4 per staged chunk (32 KiB)
-    constexpr int EPI16 = 32 * 36 / 4;         // uint4 per wave for the epilogue transpose
-    constexpr int SCRATCH16 = WAVES * EPI16 > CHUNK16 ? WAVES * EPI16 : CHUNK16;
-    if (st && st->done) return;
-    __shared__ uint4 lds[SCRATCH16];
-    const int s = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (bounds) {
-        // Pruned engine.  Every query of this block already has a target within sqrt(ub)
-        // (its previous neighbour, re-measured exactly after the pose update), and no target
-        // of this split is closer to any of them than the gap between the two bounding
-        // boxes: if gap^2 > ub, strictly, the split cannot hold a nearest neighbour (nor an
-        // equal-distance one), so the whole workgroup only writes "no candidate".
-        const BlockBounds &bb = bounds[blockIdx.x];
-        const SplitFrame &sf = frames[s];
-        double g2 = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double g1 = bb.lo[a] - sf.hi[a], g3 = sf.lo[a] - bb.hi[a];
-            const double g = g1 > g3 ? g1 : g3;
-            g2 += g > 0.0 ? g * g : 0.0;
-        }
-        if (g2 * (1.0 - 1e-12) > bb.ub * (1.0 + 1e-12)) {
-            const int iq = blockIdx.x * (kTile * QT * WAVES) + threadIdx.x;
-            if (MODE == 0 && iq < n) coarse[(size_t)s * n + iq] = make_float2(kBig, kBig);
-            if (threadIdx.x == 0 && pruned_count) atomicAdd(pruned_count, 1ull);
-            return; // workgroup-uniform
-        }
-    }
-    const int q0 = (blockIdx.x * WAVES + wave) * (kTile * QT);
+    const int q0 = (bx * WAVES + wave) * (kTile * QT);
     const double c0 = frames[s].c[0], c1 = frames[s].c[1], c2 = frames[s].c[2];
 
     // A operands.  Each lane builds the 16-slot bf16 row of ONE query (lane-per-query:
@@ -450,7 +423,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
         const int iq = q0 + t * 32 + ql;
         if (MODE == 1) {
             if (iq < n) {
-                float4 *dst = reinterpret_cast<float4 *>(slotmin + (size_t)iq * (gridDim.y * kCols) + s * kCols + half * 16);
+                float4 *dst = reinterpret_cast<float4 *>(slotmin + (size_t)iq * (nsplits * kCols) + s * kCols + half * 16);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dst[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
             }
@@ -472,6 +445,54 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     }
 }
 
+template <int WAVES>
+struct CoarseLds {
+    static constexpr int CHUNK16 = kChunkTiles * 64;
+    static constexpr int EPI16 = 32 * 36 / 4;  // uint4 per wave for the epilogue transpose
+    static constexpr int SCRATCH16 = WAVES * EPI16 > CHUNK16 ? WAVES * EPI16 : CHUNK16;
+};
+
+// all pairs: grid (query blocks, splits)
+template <int MODE, int QT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
+    const double *__restrict__ qry, int n, const uint4 *__restrict__ Bpack,
+    const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/,
+    float *__restrict__ slotmin /*[n][splits*32]*/, const IcpState *__restrict__ st)
+{
+    static_assert(QT % 2 == 0, "operands are staged 64 queries at a time");
+    if (st && st->done) return;
+    __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
+    coarse_unit<MODE, QT, WAVES>(lds, blockIdx.x, blockIdx.y, gridDim.y, qry, n, Bpack, frames, coarse, slotmin);
+}
+
+// Pruned engine: the units that survived the box test (k_transform_bounds) are listed in
+// `work` (unit = block * nsplits + split, any order); a fixed grid strides over the list, so
+// no workgroup is launched for a culled unit.  `count_next` is the counter the NEXT list
+// will be appended to (by the k_transform_bounds that follows this pass): nobody reads or
+// writes it while this kernel runs, so it is cleared here.
+template <int QT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nn_coarse_list(
+    const double *__restrict__ qry, int n, const uint4 *__restrict__ Bpack,
+    const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/, int nsplits,
+    const unsigned *__restrict__ work, const unsigned *__restrict__ count, unsigned *__restrict__ count_next,
+    unsigned total_units, unsigned long long *__restrict__ culled_count, const IcpState *__restrict__ st)
+{
+    if (st && st->done) return;
+    __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
+    const unsigned cnt = *count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *count_next = 0u;
+        if (culled_count) atomicAdd(culled_count, (unsigned long long)(total_units - cnt));
+    }
+#pragma unroll 1
+    for (unsigned w = blockIdx.x; w < cnt; w += gridDim.x) {
+        const unsigned unit = (unsigned)__builtin_amdgcn_readfirstlane((int)work[w]); // uniform: keep it scalar
+        const int bx = (int)(unit / (unsigned)nsplits), s = (int)(unit % (unsigned)nsplits);
+        coarse_unit<0, QT, WAVES>(lds, bx, s, nsplits, qry, n, Bpack, frames, coarse, nullptr);
+        __syncthreads(); // the epilogue's LDS is the next unit's operand buffer
+    }
+}
+
 // ---- pose update + block bounds (pruned engine) ---------------------------------------------------
 // out[i] = T * in[src(i)] like k_transform (icp.hpp:174-176,225-226), src(i) = perm[i] when a
 // permutation is given (Morton order of the source, applied once with the initial transform);
@@ -480,7 +501,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
 __global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
     const double *in, const unsigned *__restrict__ perm, double *out, int n,
     const IcpState *__restrict__ st, int which, int honour_done, const double *__restrict__ tgt,
-    const int *__restrict__ prev_idx, int m, BlockBounds *__restrict__ bounds)
+    const int *__restrict__ prev_idx, int m, const SplitFrame *__restrict__ frames, int nsplits,
+    int *__restrict__ blk_cnt, int *__restrict__ blk_list /*[blocks][nsplits]*/,
+    unsigned *__restrict__ work, unsigned *__restrict__ work_count)
 {
     static_assert(kCoarseQueries == 512, "one block of this kernel == one query block of k_nn_coarse");
     if (honour_done && st->done) return;
@@ -525,6 +548,7 @@ __global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
         red[wave][6] = ub;
     }
     __syncthreads();
+    __shared__ BlockBounds sb;
     if (threadIdx.x == 0) {
         BlockBounds b;
         for (int a = 0; a < 3; ++a) {
@@ -540,7 +564,44 @@ __global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
             b.ub = red[w][6] > b.ub ? red[w][6] : b.ub;
         }
         b.pad = 0.0;
-        bounds[blockIdx.x] = b;
+        sb = b;
+    }
+    __syncthreads();
+    // Cull.  Every query of this block has a target within sqrt(ub) (its previous neighbour,
+    // re-measured exactly above), and no target of split s is closer to any of them than the
+    // gap between the two bounding boxes: if gap^2 > ub, strictly (with a margin for the
+    // roundings of the test itself), split s holds neither a nearest neighbour nor an
+    // equally near one.  Survivors go, in ascending order, to the block's list (read by the
+    // resolve) and, in any order, to the pass's work list (read by k_nn_coarse_list).
+    if (wave == 0) {
+        const int b = blockIdx.x;
+        int base = 0;
+        for (int s0 = 0; s0 < nsplits; s0 += 64) {
+            const int s = s0 + lane;
+            bool act = false;
+            if (s < nsplits) {
+                double g2 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double g1 = sb.lo[a] - frames[s].hi[a], g3 = frames[s].lo[a] - sb.hi[a];
+                    const double g = g1 > g3 ? g1 : g3;
+                    g2 += g > 0.0 ? g * g : 0.0;
+                }
+                act = !(g2 * (1.0 - 1e-12) > sb.ub * (1.0 + 1e-12));
+            }
+            const unsigned long long mask = __ballot(act);
+            const int cnt = __popcll(mask);
+            unsigned gbase = 0;
+            if (lane == 0 && cnt) gbase = atomicAdd(work_count, (unsigned)cnt);
+            gbase = __shfl(gbase, 0, 64);
+            if (act) {
+                const int r = __popcll(mask & ((1ull << lane) - 1ull));
+                blk_list[(size_t)b * nsplits + base + r] = s;
+                work[gbase + r] = (unsigned)b * (unsigned)nsplits + (unsigned)s;
+            }
+            base += cnt;
+        }
+        if (lane == 0) blk_cnt[b] = base;
     }
 }
 
@@ -615,12 +676,19 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
                                                     const double *__restrict__ tgt_orig,
                                                     const double *__restrict__ nrm,
                                                     double *__restrict__ partials,
+                                                    const int *__restrict__ blk_cnt,
+                                                    const int *__restrict__ blk_list,
                                                     const IcpState *__restrict__ st)
 {
     if (st && st->done) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ql = lane & 15, quarter = lane >> 4;
     const int qbase = (blockIdx.x * 4 + wave) * kResolveQ;
+    // pruned engine: only the splits on the query block's list were evaluated (the 16 queries
+    // of a wave share a block); otherwise all of them
+    static_assert(kCoarseQueries % kResolveQ == 0, "a wave's queries share a coarse block");
+    const int *slist = blk_list ? blk_list + (size_t)(qbase / kCoarseQueries) * splits : nullptr;
+    const int nact = blk_list ? (qbase < n ? blk_cnt[qbase / kCoarseQueries] : 0) : splits;
     const int i = qbase + ql; // waves past the end run on a clamped query and write nothing
     const bool valid = i < n;
     const int ic = valid ? i : n - 1;
@@ -629,7 +697,8 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
     // phase 1: smallest coarse value over the splits (each quarter takes every 4th split)
     float best = kBig;
     int bs = 0;
-    for (int s = quarter; s < splits; s += 4) {
+    for (int e = quarter; e < nact; e += 4) {
+        const int s = slist ? slist[e] : e;
         const float v = coarse[(size_t)s * n + ic].x;
         if (v < best) {
             best = v;
@@ -690,11 +759,13 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
     // phase 3: certificate, split by split (tau depends on the split's frame)
     const double sq = sqrt(bd);
     unsigned extra_slots = 0, extra_splits = 0;
-    for (int s0 = 0; s0 < splits; s0 += 4) {
-        const int s = s0 + quarter;
+    for (int e0 = 0; e0 < nact; e0 += 4) {
+        const int e = e0 + quarter;
+        int s = 0;
         bool whole = false, slot = false;
         float2 v = make_float2(kBig, kBig);
-        if (s < splits && valid) {
+        if (e < nact && valid) {
+            s = slist ? slist[e] : e;
             v = coarse[(size_t)s * n + ic];
             const float tauf = split_tau(px, py, pz, frames[s], bd, sq);
             whole = v.y <= tauf;                       // a second column is inside the bound
@@ -707,7 +778,7 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
             const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
             const int w = __shfl((int)whole, L, 64);
             const int c = __shfl((int)(__float_as_uint(v.x) & 31u), L, 64);
-            const int sL = s0 + (L >> 4);
+            const int sL = __shfl(s, L, 64);
             double d = 1.7976931348623157e308;
             int j = 0x7fffffff;
             if (w) scan_range(sorted, perm, m, ms, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
