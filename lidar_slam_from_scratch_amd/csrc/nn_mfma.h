@@ -871,19 +871,28 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
 // written closest first -- the order kdtree.hpp:72-76 returns and icp.hpp:41-51 sums in.
 constexpr int kKnnCap = 256;        // candidates per row held in LDS (more: the bound is tightened and the row redone)
 constexpr int kKnnMaxSplits = 256;  // per-split bounds cached in LDS (512k targets); beyond: recomputed
-constexpr int kKnnRegSlots = 32;    // slot minima per lane kept in registers (2048 slots = 131k targets)
+#ifndef ICPMI_KNN_REGSLOTS
+#define ICPMI_KNN_REGSLOTS 32
+#endif
+constexpr int kKnnRegSlots = ICPMI_KNN_REGSLOTS;    // slot minima per lane kept in registers (2048 slots = 131k targets)
 
-// k-th smallest (k = kk, 1-based) of one double per lane; DBL_MAX when fewer than kk are finite
-__device__ __forceinline__ double wave_kth_smallest(double v, int lane, int kk)
+// Ascending bitonic sort of one value per lane (21 compare-exchange steps); lane i ends up
+// with the i-th smallest.  Used for "k-th smallest of 64": a rank-by-counting loop costs 64
+// broadcast + compare rounds, several times this.
+template <typename T>
+__device__ __forceinline__ T wave_sort_asc(T v, int lane)
 {
-    int rank = 0;
-#pragma unroll 8
-    for (int L = 0; L < 64; ++L) {
-        const double o = __shfl(v, L, 64);
-        rank += (o < v || (o == v && L < lane)) ? 1 : 0;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const T o = __shfl_xor(v, j, 64);
+            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+            const T mn = o < v ? o : v, mx = o < v ? v : o;
+            v = (lower == up) ? mn : mx;
+        }
     }
-    const unsigned long long who = __ballot(rank == kk - 1);
-    return __shfl(v, who ? __ffsll((long long)who) - 1 : 0, 64);
+    return v;
 }
 
 __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ pts, int row0, int nrows,
@@ -897,6 +906,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     __shared__ double cand_d[4][kKnnCap];
     __shared__ int cand_j[4][kKnnCap];
     __shared__ float tau_sp[4][kKnnMaxSplits]; // per-split bound on the coarse value, per row
+    __shared__ int cand_r[4][kKnnCap], owner[4][kKnnCap]; // distance-only rank of a candidate; who claimed a rank
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int local = blockIdx.x * 4 + wave;
     if (local >= nrows) return; // wave-uniform
@@ -928,35 +938,22 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             lslot = e;
         }
     }
-    // bound (a): k-th smallest of the 64 lane minima (ties ordered by lane)
-    int rank = 0;
-#pragma unroll 8
-    for (int L = 0; L < 64; ++L) {
-        const float v = __shfl(lmin, L, 64);
-        rank += (v < lmin || (v == lmin && L < lane)) ? 1 : 0;
-    }
-    // (a row with NaN coordinates ranks every lane 0: the ballots may be empty -> lane 0)
-    const unsigned long long whoK = __ballot(rank == kk - 1), who0 = __ballot(rank == 0);
-    const float tS = __shfl(lmin, whoK ? __ffsll((long long)whoK) - 1 : 0, 64);
-    const int bslot = __shfl(lslot, who0 ? __ffsll((long long)who0) - 1 : 0, 64);
-    double a;
+    // best slot: lane with the smallest minimum (ties: lowest lane)
+    int bslot;
     {
-        const SplitFrame &f = frames[lslot / kCols];
-        const double dx = px - f.c[0], dy = py - f.c[1], dz = pz - f.c[2];
-        a = rank < kk ? sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + f.rho : 0.0;
+        float bv = lmin;
+        int bl = lane;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const double o = __shfl_xor(a, off, 64);
-            a = o > a ? o : a;
+            const float ov = __shfl_xor(bv, off, 64);
+            const int ol = __shfl_xor(bl, off, 64);
+            if (ov < bv || (ov == bv && ol < bl)) {
+                bv = ov;
+                bl = ol;
+            }
         }
+        bslot = __shfl(lslot, bl, 64);
     }
-    const double u = 5.9604644775390625e-08;
-    const double eps = kReprEps * a * (1.0 + 1e-6);
-    const double A = kArithBound * u * a * a;
-    const double ts = tS > 0.f ? (double)tS * (1.0 + 1e-6) : 0.0;
-    const double xr = eps + sqrt(eps * eps + (ts + eps * eps + A)); // sqrt(dmax)
-    const double dmax = tS >= kBig ? 1.0e300 : xr * xr * (1.0 + 1e-9);
-
     // bound (b): exact scan of the best slot (kSlotTargets / 64 targets per lane); when a slot
     // is a single 64-run the 64 sorted positions after it (the next slot) also tighten the
     // bound -- those are collected later through the normal path
@@ -980,8 +977,31 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     double lbest = dloc[0];
 #pragma unroll
     for (int c = 1; c < kBnd; ++c) lbest = dloc[c] < lbest ? dloc[c] : lbest;
-    const double t1 = wave_kth_smallest(lbest, lane, kk);
-    double T = t1 < dmax ? t1 : dmax;
+    const double t1 = __shfl(wave_sort_asc(lbest, lane), kk - 1, 64);
+    double T = t1;
+    { // both bounds matter: on the 100k uniform cloud either one alone makes this kernel 2-3x slower
+        // bound (a): k-th smallest of the 64 lane minima; the lanes at or under it (k of them, more
+        // on ties: only makes the frame term larger) set the frame term
+        const float tS = __shfl(wave_sort_asc(lmin, lane), kk - 1, 64);
+        double a;
+        {
+            const SplitFrame &f = frames[lslot / kCols];
+            const double dx = px - f.c[0], dy = py - f.c[1], dz = pz - f.c[2];
+            a = lmin <= tS ? sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + f.rho : 0.0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_xor(a, off, 64);
+                a = o > a ? o : a;
+            }
+        }
+        const double u = 5.9604644775390625e-08;
+        const double eps = kReprEps * a * (1.0 + 1e-6);
+        const double A = kArithBound * u * a * a;
+        const double ts = tS > 0.f ? (double)tS * (1.0 + 1e-6) : 0.0;
+        const double xr = eps + sqrt(eps * eps + (ts + eps * eps + A)); // sqrt(dmax)
+        const double dmax = tS >= kBig ? 1.0e300 : xr * xr * (1.0 + 1e-9);
+        T = T < dmax ? T : dmax; // (NaN rows: T becomes dmax)
+    }
 
     // candidates: the best slot's targets under T, then every other slot under its split's
     // bound.  If more than kKnnCap turn up, the k-th smallest of those already held is a
@@ -1081,7 +1101,27 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         return;
     }
     __builtin_amdgcn_wave_barrier();
-    // rank by (distance, original index); the k smallest go out closest first
+    // Rank the candidates by (distance, original index); the k smallest go out closest first.
+    // Fast pass: count strictly smaller distances only (one compare per pair).  Without equal
+    // distances that count IS the rank; candidates with equal distance get the same count,
+    // which the owner table exposes -- then the full (distance, index) order is evaluated.
+    bool clash = false;
+    for (int e = lane; e < total; e += 64) {
+        const double d = cand_d[wave][e];
+        int r = 0;
+        for (int f = 0; f < total; ++f) r += cand_d[wave][f] < d ? 1 : 0;
+        cand_r[wave][e] = r;
+        owner[wave][r] = e;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < total; e += 64) clash |= owner[wave][cand_r[wave][e]] != e;
+    if (__ballot(clash) == 0ull) {
+        for (int e = lane; e < total; e += 64) {
+            const int r = cand_r[wave][e];
+            if (r < k) knn_idx[(size_t)i * k + r] = cand_j[wave][e];
+        }
+        return;
+    }
     for (int e = lane; e < total; e += 64) {
         const double d = cand_d[wave][e];
         const int j = cand_j[wave][e];

@@ -14,3 +14,10 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for k, cs in acc.items():
         for c, v in cs.items():
             print("%-50s %-28s n=%4d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
+
+import sqlite3
+for f in glob.glob(d + "/**/*_results.db", recursive=True):
+    print("== kernel stats (rocpd)", f)
+    db = sqlite3.connect(f)
+    for name, calls, total, avg, pct in db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+        print("%-60s calls %5d avg %10.1f us total %10.1f us %5.2f%%" % (name[:60], calls, avg, total, pct))

@@ -6,7 +6,8 @@ Usage: python scripts/shard_overhead.py [engine]"""
 import sys, time, json
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lidar_slam_from_scratch_amd import capi, synth
 
 eng = int(sys.argv[1]) if len(sys.argv) > 1 else 0
