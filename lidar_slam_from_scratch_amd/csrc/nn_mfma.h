@@ -611,7 +611,9 @@ __device__ __forceinline__ float split_tau(double px, double py, double pz, cons
                                            double sqrt_d)
 {
     const double dx = px - f.c[0], dy = py - f.c[1], dz = pz - f.c[2];
-    const double a = sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + f.rho;
+    // |p - c| only has to be an upper bound good to ~1e-6: fp32 square root (v_sqrt_f32, 1 ulp;
+    // the conversion adds 2^-24) under the 1e-6 inflation instead of a ~35-instruction fp64 one
+    const double a = (double)__builtin_amdgcn_sqrtf((float)((dx * dx + dy * dy) + dz * dz)) * (1.0 + 1e-6) + f.rho;
     const double u = 5.9604644775390625e-08; // 2^-24
     const double eps = kReprEps * a * (1.0 + 1e-6);
     double tau = d + eps * (2.0 * sqrt_d + eps) + kArithBound * u * a * a;
@@ -839,13 +841,24 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
             for (int r = 0; r < 6; ++r) acc[21 + r] = J[r] * b;
             acc[27] = b * b;
         }
+        // 16 rows of 28 terms per wave -> LDS (row stride 29: conflict-free), then lane l sums
+        // column l & 31 over the 8 rows of half l >> 5 and the halves meet with one exchange
+        __shared__ double jrow[4][16][29];
         __shared__ double red[4][28];
+        if (quarter == 0) {
 #pragma unroll
-        for (int e = 0; e < 28; ++e) {
-            double v = acc[e];
+            for (int e = 0; e < 28; ++e) jrow[wave][ql][e] = acc[e];
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int c = lane & 31, h = lane >> 5;
+            double v = 0.0;
+            if (c < 28) {
 #pragma unroll
-            for (int x = 1; x < 16; x <<= 1) v += __shfl_xor(v, x, 64); // only lanes 0..15 hold data
-            if (lane == 0) red[wave][e] = v;
+                for (int r = 0; r < 8; ++r) v += jrow[wave][h * 8 + r][c];
+            }
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 28) red[wave][lane] = v;
         }
         __syncthreads();
         if (threadIdx.x < 28) {
