@@ -575,6 +575,30 @@ __global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
     // resolve) and, in any order, to the pass's work list (read by k_nn_coarse_list).
     if (wave == 0) {
         const int b = blockIdx.x;
+        // A second bound that needs no previous neighbour (first pass, rows whose neighbour is
+        // unknown): every split holds a target, and that target is no farther from any query of
+        // the block than the largest distance between the two boxes.
+        double ub = sb.ub;
+        {
+            double far2 = __builtin_inf();
+            for (int s = lane; s < nsplits; s += 64) {
+                double f2 = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double f1 = sb.hi[a] - frames[s].lo[a], f3 = frames[s].hi[a] - sb.lo[a];
+                    const double f = f1 > f3 ? f1 : f3;
+                    f2 += f * f;
+                }
+                far2 = f2 < far2 ? f2 : far2;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_xor(far2, off, 64);
+                far2 = o < far2 ? o : far2;
+            }
+            far2 *= 1.0 + 1e-12;
+            ub = far2 < ub ? far2 : ub;
+        }
         int base = 0;
         for (int s0 = 0; s0 < nsplits; s0 += 64) {
             const int s = s0 + lane;
@@ -587,7 +611,7 @@ __global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
                     const double g = g1 > g3 ? g1 : g3;
                     g2 += g > 0.0 ? g * g : 0.0;
                 }
-                act = !(g2 * (1.0 - 1e-12) > sb.ub * (1.0 + 1e-12));
+                act = !(g2 * (1.0 - 1e-12) > ub * (1.0 + 1e-12));
             }
             const unsigned long long mask = __ballot(act);
             const int cnt = __popcll(mask);
