@@ -288,8 +288,9 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
         if (pruned_pass >= 0) {
             // pass p consumes the list counted in work_cnt[p & 1] and clears the other counter
             unsigned *cnt = (unsigned *)((char *)ctx->nn_misc.p + 160);
-            hipLaunchKernelGGL((k_nn_coarse_list<kCoarseQT, kCoarseWaves>), dim3(2 * ctx->cu_count), dim3(kCoarseThreads), 0,
-                               ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames, (float2 *)ctx->coarse.p, splits,
+            hipLaunchKernelGGL((k_nn_coarse_list<0, false, kCoarseQT, kCoarseWaves>), dim3(2 * ctx->cu_count), dim3(kCoarseThreads), 0,
+                               ctx->stream, d_qry, n, (size_t)0, (const uint4 *)ctx->bpack.p, frames, (float2 *)ctx->coarse.p,
+                               (float *)nullptr, splits,
                                (const unsigned *)ctx->work.p, (const unsigned *)(cnt + (pruned_pass & 1)),
                                cnt + ((pruned_pass + 1) & 1),
                                (unsigned)(((n + kCoarseQueries - 1) / kCoarseQueries) * splits), counters + 2, st);
@@ -344,8 +345,11 @@ int reduce_blocks(const icpmi_ctx *ctx, int n)
 // normals of rows [row0,row1) of d_pts against all m points (icp.hpp:23-67): k-NN lists
 // (MFMA coarse + exact resolve, or the exact fp64 kernel) then PCA.  prepare_nn() must have
 // run for d_pts.
+// With the pruned engine (`by_sorted_row`), [row0, row1) are positions in the Morton-sorted
+// target (row0 a multiple of 64) and `scatter` selects where a normal goes: to its point's row
+// of d_normals (m rows), or to its sorted row (what a rank contributes to the all-gather).
 int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, int row1,
-                   double *d_normals)
+                   double *d_normals, bool by_sorted_row = false, bool scatter = true)
 {
     const int rows = row1 - row0;
     if (rows <= 0) return ICPMI_OK;
@@ -356,29 +360,60 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
     constexpr int BLOCK = 128;
     const size_t smem = (size_t)k * BLOCK * (sizeof(double) + sizeof(int));
     const bool mfma = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= 4 * kSplitTargets;
+    const unsigned *perm = mfma ? (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m : nullptr;
+    if (by_sorted_row && !mfma) return fail(ctx, ICPMI_ERR_ARG, "sorted-row normals need the MFMA engine's sorted target");
     StageTimer t(ctx, ST_NORMALS);
     if (mfma) {
         const int splits = ctx->nn_splits, nslots = splits * kCols;
-        // bound the slot-minimum buffer (4 B x nslots per row) to ~1 GiB by chunking the rows
-        long chunk = ((1l << 30) / ((long)nslots * 4)) / kCoarseQueries * kCoarseQueries;
+        // bound the slot-minimum buffer (4 B x nslots per row) by chunking the rows: ~1 GiB, or
+        // ~4 GiB when culling leaves most of it untouched (the pruned engine writes only the
+        // listed splits of a row, the layout stays dense)
+        const long budget = by_sorted_row ? (4l << 30) : (1l << 30);
+        long chunk = (budget / ((long)nslots * 4)) / kCoarseQueries * kCoarseQueries;
         chunk = std::max<long>(kCoarseQueries, std::min<long>(chunk, ((long)rows + kCoarseQueries - 1) / kCoarseQueries * kCoarseQueries));
         if ((rc = reserve(ctx, ctx->slotmin, sizeof(float) * (size_t)chunk * nslots))) return rc;
         if ((rc = reserve(ctx, ctx->fb_list, sizeof(int) * ((size_t)rows + 16)))) return rc;
         int *fb_count = (int *)ctx->fb_list.p, *fb_list = fb_count + 16;
         HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, sizeof(int), s));
         const SplitFrame *frames = (const SplitFrame *)ctx->frames.p;
-        const unsigned *perm = (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m;
+        const double *sorted = (const double *)ctx->tgt_sorted.p;
+        const int cblocks = (int)(chunk / kCoarseQueries);
+        int *blk_cnt = nullptr, *blk_list = nullptr;
+        unsigned *work = nullptr, *work_cnt = nullptr;
+        if (by_sorted_row) {
+            if ((rc = reserve(ctx, ctx->blk_lists, sizeof(int) * (size_t)cblocks * ((size_t)splits + 1)))) return rc;
+            if ((rc = reserve(ctx, ctx->work, sizeof(unsigned) * (size_t)cblocks * (size_t)splits))) return rc;
+            blk_cnt = (int *)ctx->blk_lists.p;
+            blk_list = blk_cnt + cblocks;
+            work = (unsigned *)ctx->work.p;
+            work_cnt = (unsigned *)((char *)ctx->nn_misc.p + 168);
+        }
         for (long c0 = row0; c0 < row1; c0 += chunk) {
             const int nq = (int)std::min<long>(chunk, row1 - c0);
-            hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves>), dim3((nq + kCoarseQueries - 1) / kCoarseQueries, splits),
-                               dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
-                               frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
-            hipLaunchKernelGGL(k_knn_resolve, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq,
-                               (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots,
-                               frames, knn, fb_list, fb_count);
+            const int nblk = (nq + kCoarseQueries - 1) / kCoarseQueries;
+            if (by_sorted_row) {
+                HIP_TRY(ctx, hipMemsetAsync(work_cnt, 0, sizeof(unsigned), s));
+                hipLaunchKernelGGL(k_knn_block_bounds, dim3(nblk), dim3(kCoarseQueries), 0, s, sorted, m, ctx->nn_ms, (int)c0, nq,
+                                   std::min(k, 64), frames, splits, blk_cnt, blk_list, work, work_cnt);
+                hipLaunchKernelGGL((k_nn_coarse_list<1, true, kCoarseQT, kCoarseWaves>), dim3(2 * ctx->cu_count), dim3(kCoarseThreads),
+                                   0, s, sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, (float2 *)nullptr,
+                                   (float *)ctx->slotmin.p, splits, (const unsigned *)work, (const unsigned *)work_cnt,
+                                   (unsigned *)nullptr, 0u, (unsigned long long *)nullptr, (const IcpState *)nullptr);
+                hipLaunchKernelGGL(k_knn_resolve<true>, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq, sorted, perm, m,
+                                   ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots, frames, knn, fb_list, fb_count,
+                                   (const int *)blk_cnt, (const int *)blk_list);
+            } else {
+                hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves>), dim3(nblk, splits),
+                                   dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
+                                   frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
+                hipLaunchKernelGGL(k_knn_resolve<false>, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq, sorted, perm, m,
+                                   ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots, frames, knn, fb_list, fb_count,
+                                   (const int *)nullptr, (const int *)nullptr);
+            }
         }
         hipLaunchKernelGGL(k_knn_exact_rows, dim3(1024), dim3(256), (size_t)k * 256 * (sizeof(double) + sizeof(int)),
-                           s, d_pts, m, k, (const int *)fb_list, (const int *)fb_count, knn);
+                           s, d_pts, m, k, (const int *)fb_list, (const int *)fb_count, knn,
+                           by_sorted_row ? perm : (const unsigned *)nullptr);
         if (ctx->opt.profile) { // visibility only: how many rows took the exact path
             int cnt = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&cnt, fb_count, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -390,7 +425,8 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
                            d_pts, m, k, row0, row1, (const int *)nullptr, (const int *)nullptr, knn);
     }
     hipLaunchKernelGGL(k_normals_from_knn, dim3((rows + 255) / 256), dim3(256), 0, s, d_pts, m, k, row0, row1,
-                       (const int *)knn, d_normals);
+                       (const int *)knn, d_normals, by_sorted_row ? perm : (const unsigned *)nullptr,
+                       (int)(by_sorted_row && scatter));
     HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;
 }
@@ -513,18 +549,26 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // normals of the target (icp.hpp:169-171).  With several ranks each computes a slice of
     // rows against the full target and the slices are all-gathered.
     const bool sharded = ctx->comm != nullptr || ctx->cb_allreduce != nullptr; // exchanges on, even for 1 rank
+    // pruned engine: rows are taken in the target's Morton order, so that a block's neighbours
+    // lie in few splits (launch_normals); a rank's slice is then a range of sorted positions
+    const bool sorted_rows = fused && ctx->nn_pruned && ctx->opt.normal_k <= 32 && m >= 4 * kSplitTargets;
     if (sharded) {
-        const int per = (m + ctx->n_ranks - 1) / ctx->n_ranks;
+        int per = (m + ctx->n_ranks - 1) / ctx->n_ranks;
+        if (sorted_rows) per = (per + kCoarseQueries - 1) / kCoarseQueries * kCoarseQueries; // whole blocks (and slots) per rank
         if ((rc = reserve(ctx, ctx->stage_a, sizeof(double) * 3 * (size_t)per * ctx->n_ranks))) return rc;
         double *gathered = (double *)ctx->stage_a.p;
-        const int row0 = std::min(m, ctx->rank * per), row1 = std::min(m, row0 + per);
+        const int row0 = (int)std::min<long>(m, (long)ctx->rank * per), row1 = (int)std::min<long>(m, (long)row0 + per);
         // rows land at their global offset inside `gathered`, so the gather is in place
-        if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, row0, row1, gathered))) return rc;
+        if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, row0, row1, gathered, sorted_rows, false))) return rc;
         if ((rc = exchange_allgather(ctx, gathered, 3 * (size_t)per))) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(nrm, gathered, sizeof(double) * 3 * (size_t)m,
-                                    hipMemcpyDeviceToDevice, s));
+        if (sorted_rows)
+            hipLaunchKernelGGL(k_scatter_rows, dim3((m + 255) / 256), dim3(256), 0, s, (const double *)gathered,
+                               (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m, m, nrm);
+        else
+            HIP_TRY(ctx, hipMemcpyAsync(nrm, gathered, sizeof(double) * 3 * (size_t)m,
+                                        hipMemcpyDeviceToDevice, s));
     } else {
-        if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, 0, m, nrm))) return rc;
+        if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, 0, m, nrm, sorted_rows, true))) return rc;
     }
 
     // Pruned engine: the source is put in Morton order once (a rigid motion keeps neighbours
@@ -911,7 +955,8 @@ int icpmi_estimate_normals(icpmi_ctx *ctx, const double *points_xyz, int64_t n, 
     hipStream_t s = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.p, points_xyz, sizeof(double) * 3 * (size_t)m, hipMemcpyHostToDevice, s));
     if ((rc = prepare_nn(ctx, (const double *)ctx->stage_c.p, m, m))) return rc;
-    if ((rc = launch_normals(ctx, (const double *)ctx->stage_c.p, m, k, 0, m, (double *)ctx->nrm.p))) return rc;
+    const bool sorted_rows = ctx->nn_pruned && ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= 4 * kSplitTargets;
+    if ((rc = launch_normals(ctx, (const double *)ctx->stage_c.p, m, k, 0, m, (double *)ctx->nrm.p, sorted_rows, true))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(normals_xyz, ctx->nrm.p, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     harvest_profile(ctx);

@@ -315,9 +315,11 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
 // scripts/micro/README.md: issuing a tile's min3 one tile behind its MFMAs, keeping the next B chunk
 // in flight in registers, QT = 4: none beat this form, all cost occupancy.)
 // One (query block, split) unit of the coarse pass: 512 queries against 2048 targets.
-template <int MODE, int QT, int WAVES>
+// QS = 0: queries are rows of an N x 3 array; QS > 0 is not a template value but the runtime
+// component stride of an SoA array (x[0..n) | y | z, the layout of the sorted target) when QSOA.
+template <int MODE, int QT, int WAVES, bool QSOA = false>
 __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int s, const int nsplits,
-                                            const double *__restrict__ qry, const int n,
+                                            const double *__restrict__ qry, const int n, const size_t qstride,
                                             const uint4 *__restrict__ Bpack,
                                             const SplitFrame *__restrict__ frames,
                                             float2 *__restrict__ coarse, float *__restrict__ slotmin)
@@ -338,8 +340,9 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
 #pragma unroll
         for (int gq = 0; gq < QT / 2; ++gq) {
             const int iq = q0 + gq * 64 + lane < n ? q0 + gq * 64 + lane : n - 1;
-            const float px = (float)(qry[3 * iq] - c0), py = (float)(qry[3 * iq + 1] - c1),
-                        pz = (float)(qry[3 * iq + 2] - c2);
+            const float px = (float)((QSOA ? qry[iq] : qry[3 * iq]) - c0),
+                        py = (float)((QSOA ? qry[qstride + iq] : qry[3 * iq + 1]) - c1),
+                        pz = (float)((QSOA ? qry[2 * qstride + iq] : qry[3 * iq + 2]) - c2);
             unsigned xh, xm, yh, ym, zh, zm;
             split2(px, xh, xm);
             split2(py, yh, ym);
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     static_assert(QT % 2 == 0, "operands are staged 64 queries at a time");
     if (st && st->done) return;
     __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
-    coarse_unit<MODE, QT, WAVES>(lds, blockIdx.x, blockIdx.y, gridDim.y, qry, n, Bpack, frames, coarse, slotmin);
+    coarse_unit<MODE, QT, WAVES>(lds, blockIdx.x, blockIdx.y, gridDim.y, qry, n, 0, Bpack, frames, coarse, slotmin);
 }
 
 // Pruned engine: the units that survived the box test (k_transform_bounds) are listed in
@@ -470,10 +473,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
 // no workgroup is launched for a culled unit.  `count_next` is the counter the NEXT list
 // will be appended to (by the k_transform_bounds that follows this pass): nobody reads or
 // writes it while this kernel runs, so it is cleared here.
-template <int QT, int WAVES>
+template <int MODE, bool QSOA, int QT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nn_coarse_list(
-    const double *__restrict__ qry, int n, const uint4 *__restrict__ Bpack,
-    const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/, int nsplits,
+    const double *__restrict__ qry, int n, size_t qstride, const uint4 *__restrict__ Bpack,
+    const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/,
+    float *__restrict__ slotmin /*[n][nsplits*32], MODE 1*/, int nsplits,
     const unsigned *__restrict__ work, const unsigned *__restrict__ count, unsigned *__restrict__ count_next,
     unsigned total_units, unsigned long long *__restrict__ culled_count, const IcpState *__restrict__ st)
 {
@@ -481,16 +485,59 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
     __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
     const unsigned cnt = *count;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *count_next = 0u;
+        if (count_next) *count_next = 0u;
         if (culled_count) atomicAdd(culled_count, (unsigned long long)(total_units - cnt));
     }
 #pragma unroll 1
     for (unsigned w = blockIdx.x; w < cnt; w += gridDim.x) {
         const unsigned unit = (unsigned)__builtin_amdgcn_readfirstlane((int)work[w]); // uniform: keep it scalar
         const int bx = (int)(unit / (unsigned)nsplits), s = (int)(unit % (unsigned)nsplits);
-        coarse_unit<0, QT, WAVES>(lds, bx, s, nsplits, qry, n, Bpack, frames, coarse, nullptr);
+        coarse_unit<MODE, QT, WAVES, QSOA>(lds, bx, s, nsplits, qry, n, qstride, Bpack, frames, coarse, slotmin);
         __syncthreads(); // the epilogue's LDS is the next unit's operand buffer
     }
+}
+
+// The box test of the pruned engine, run by one wave for query block `b` with bounding box
+// [lo, hi] and `ub` >= the squared distance within which every query of the block is known to
+// find what it looks for (its nearest target; its k-th nearest for normals).  No target of
+// split s is closer to any query of the block than the gap between the two boxes: if
+// gap^2 > ub, strictly (with a margin for the roundings of the test itself), split s holds
+// nothing that can enter the answer, not even at equal distance.  Survivors go, ascending, to
+// the block's list (read by the resolve) and, in any order, to the pass's work list (read by
+// k_nn_coarse_list).
+__device__ __forceinline__ void cull_block(const int b, const double *lo, const double *hi, const double ub,
+                                           const SplitFrame *__restrict__ frames, const int nsplits,
+                                           int *__restrict__ blk_cnt, int *__restrict__ blk_list,
+                                           unsigned *__restrict__ work, unsigned *__restrict__ work_count,
+                                           const int lane)
+{
+    int base = 0;
+    for (int s0 = 0; s0 < nsplits; s0 += 64) {
+        const int s = s0 + lane;
+        bool act = false;
+        if (s < nsplits) {
+            double g2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double g1 = lo[a] - frames[s].hi[a], g3 = frames[s].lo[a] - hi[a];
+                const double g = g1 > g3 ? g1 : g3;
+                g2 += g > 0.0 ? g * g : 0.0;
+            }
+            act = !(g2 * (1.0 - 1e-12) > ub * (1.0 + 1e-12));
+        }
+        const unsigned long long mask = __ballot(act);
+        const int cnt = __popcll(mask);
+        unsigned gbase = 0;
+        if (lane == 0 && cnt) gbase = atomicAdd(work_count, (unsigned)cnt);
+        gbase = __shfl(gbase, 0, 64);
+        if (act) {
+            const int r = __popcll(mask & ((1ull << lane) - 1ull));
+            blk_list[(size_t)b * nsplits + base + r] = s;
+            work[gbase + r] = (unsigned)b * (unsigned)nsplits + (unsigned)s;
+        }
+        base += cnt;
+    }
+    if (lane == 0) blk_cnt[b] = base;
 }
 
 // ---- pose update + block bounds (pruned engine) ---------------------------------------------------
@@ -567,14 +614,8 @@ __global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
         sb = b;
     }
     __syncthreads();
-    // Cull.  Every query of this block has a target within sqrt(ub) (its previous neighbour,
-    // re-measured exactly above), and no target of split s is closer to any of them than the
-    // gap between the two bounding boxes: if gap^2 > ub, strictly (with a margin for the
-    // roundings of the test itself), split s holds neither a nearest neighbour nor an
-    // equally near one.  Survivors go, in ascending order, to the block's list (read by the
-    // resolve) and, in any order, to the pass's work list (read by k_nn_coarse_list).
+    // cull with the tighter of two bounds (see cull_block)
     if (wave == 0) {
-        const int b = blockIdx.x;
         // A second bound that needs no previous neighbour (first pass, rows whose neighbour is
         // unknown): every split holds a target, and that target is no farther from any query of
         // the block than the largest distance between the two boxes.
@@ -599,34 +640,76 @@ __global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
             far2 *= 1.0 + 1e-12;
             ub = far2 < ub ? far2 : ub;
         }
-        int base = 0;
-        for (int s0 = 0; s0 < nsplits; s0 += 64) {
-            const int s = s0 + lane;
-            bool act = false;
-            if (s < nsplits) {
-                double g2 = 0.0;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const double g1 = sb.lo[a] - frames[s].hi[a], g3 = frames[s].lo[a] - sb.hi[a];
-                    const double g = g1 > g3 ? g1 : g3;
-                    g2 += g > 0.0 ? g * g : 0.0;
-                }
-                act = !(g2 * (1.0 - 1e-12) > ub * (1.0 + 1e-12));
-            }
-            const unsigned long long mask = __ballot(act);
-            const int cnt = __popcll(mask);
-            unsigned gbase = 0;
-            if (lane == 0 && cnt) gbase = atomicAdd(work_count, (unsigned)cnt);
-            gbase = __shfl(gbase, 0, 64);
-            if (act) {
-                const int r = __popcll(mask & ((1ull << lane) - 1ull));
-                blk_list[(size_t)b * nsplits + base + r] = s;
-                work[gbase + r] = (unsigned)b * (unsigned)nsplits + (unsigned)s;
-            }
-            base += cnt;
-        }
-        if (lane == 0) blk_cnt[b] = base;
+        cull_block(blockIdx.x, sb.lo, sb.hi, ub, frames, nsplits, blk_cnt, blk_list, work, work_count, lane);
     }
+}
+
+// Normal estimation with the pruned engine: the rows are the sorted targets themselves, so a
+// block is 512 consecutive sorted positions = 8 slots of 64.  A slot with at least k points
+// puts the k-th neighbour of each of its points (the point itself counts, kdtree.hpp:65-78)
+// within the diagonal of the slot's bounding box; the block's bound is the largest of its
+// slots' (infinite if one of them is too small to vouch for k neighbours).
+__global__ __launch_bounds__(kCoarseQueries) void k_knn_block_bounds(
+    const double *__restrict__ sorted, int m, int ms, int row0, int nrows, int kk,
+    const SplitFrame *__restrict__ frames, int nsplits, int *__restrict__ blk_cnt,
+    int *__restrict__ blk_list, unsigned *__restrict__ work, unsigned *__restrict__ work_count)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int local = blockIdx.x * kCoarseQueries + threadIdx.x;
+    const int j = row0 + local;
+    const bool valid = local < nrows && j < m;
+    double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
+    if (valid) {
+        lo[0] = hi[0] = ICPMI_SX(sorted, ms, j);
+        lo[1] = hi[1] = ICPMI_SY(sorted, ms, j);
+        lo[2] = hi[2] = ICPMI_SZ(sorted, ms, j);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double l2 = __shfl_xor(lo[a], off, 64), h2 = __shfl_xor(hi[a], off, 64);
+            lo[a] = l2 < lo[a] ? l2 : lo[a];
+            hi[a] = h2 > hi[a] ? h2 : hi[a];
+        }
+    }
+    // this wave's 64 rows are one slot of the sorted target only if the slot is complete in
+    // the cloud (row0 is a multiple of 64); rows past the chunk still belong to the slot
+    const int slot0 = row0 + blockIdx.x * kCoarseQueries + wave * 64;
+    const int in_cloud = slot0 < m ? (m - slot0 < 64 ? m - slot0 : 64) : 0;
+    const int here = __popcll(__ballot(valid));
+    double ub = 0.0;
+    if (here > 0) {
+        const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        ub = (ex * ex + ey * ey) + ez * ez;
+        ub *= 1.0 + 1e-12;
+        // fewer rows here than the slot holds in the cloud (chunk edge), or fewer than k: no bound
+        if (here < in_cloud || in_cloud < kk || !(ub == ub)) ub = __builtin_inf();
+    }
+    __shared__ double red[8][7];
+    __shared__ double sbox[7];
+    if (lane == 0) {
+        for (int a = 0; a < 3; ++a) {
+            red[wave][a] = lo[a];
+            red[wave][3 + a] = hi[a];
+        }
+        red[wave][6] = ub;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b[7];
+        for (int a = 0; a < 7; ++a) b[a] = red[0][a];
+        for (int w = 1; w < 8; ++w) {
+            for (int a = 0; a < 3; ++a) {
+                b[a] = red[w][a] < b[a] ? red[w][a] : b[a];
+                b[3 + a] = red[w][3 + a] > b[3 + a] ? red[w][3 + a] : b[3 + a];
+            }
+            b[6] = red[w][6] > b[6] ? red[w][6] : b[6];
+        }
+        for (int a = 0; a < 7; ++a) sbox[a] = b[a];
+    }
+    __syncthreads();
+    if (wave == 0) cull_block(blockIdx.x, sbox, sbox + 3, sbox[6], frames, nsplits, blk_cnt, blk_list, work, work_count, lane);
 }
 
 // ---- resolve ---------------------------------------------------------------------------------------
@@ -932,23 +1015,48 @@ __device__ __forceinline__ T wave_sort_asc(T v, int lane)
     return v;
 }
 
+// LISTED (pruned engine): the rows are SORTED positions row0.. of the target itself, only the
+// splits on the row's block list (k_knn_block_bounds) were evaluated, and the neighbour lists
+// are stored by sorted position.  Slots are then numbered locally, 32 per list entry.
+template <bool LISTED>
 __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ pts, int row0, int nrows,
                                                      const double *__restrict__ sorted,
                                                      const unsigned *__restrict__ perm, int m, int ms, int k,
                                                      const float *__restrict__ slotmin, int nslots,
                                                      const SplitFrame *__restrict__ frames,
                                                      int *__restrict__ knn_idx /*[m][k]*/,
-                                                     int *__restrict__ fb_list, int *__restrict__ fb_count)
+                                                     int *__restrict__ fb_list, int *__restrict__ fb_count,
+                                                     const int *__restrict__ blk_cnt,
+                                                     const int *__restrict__ blk_list)
 {
     __shared__ double cand_d[4][kKnnCap];
     __shared__ int cand_j[4][kKnnCap];
     __shared__ float tau_sp[4][kKnnMaxSplits]; // per-split bound on the coarse value, per row
     __shared__ int cand_r[4][kKnnCap], owner[4][kKnnCap]; // distance-only rank of a candidate; who claimed a rank
+    __shared__ int s_list[kKnnMaxSplits];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int local = blockIdx.x * 4 + wave;
+    // the four rows of a workgroup share a query block, hence its list of evaluated splits
+    static_assert(kCoarseQueries % 4 == 0, "a workgroup's rows share a coarse block");
+    const int *slist = LISTED ? blk_list + (size_t)(blockIdx.x * 4 / kCoarseQueries) * (nslots / kCols) : nullptr;
+    const int nact = LISTED ? blk_cnt[blockIdx.x * 4 / kCoarseQueries] : 0;
+    if (LISTED) {
+        for (int e = threadIdx.x; e < nact && e < kKnnMaxSplits; e += 256) s_list[e] = slist[e];
+        __syncthreads();
+    }
     if (local >= nrows) return; // wave-uniform
     const int i = row0 + local;
-    const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    if (LISTED && nact == 0) { // cannot happen for a block with points (its own split is always listed)
+        if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = i;
+        return;
+    }
+    const int ic = LISTED ? (i < m ? i : m - 1) : i;
+    const double px = LISTED ? ICPMI_SX(sorted, ms, ic) : pts[3 * i], py = LISTED ? ICPMI_SY(sorted, ms, ic) : pts[3 * i + 1],
+                 pz = LISTED ? ICPMI_SZ(sorted, ms, ic) : pts[3 * i + 2];
+    // local slot e -> global slot; local split (list entry) -> global split
+    auto gsplit = [&](int sp) -> int { return LISTED ? (sp < kKnnMaxSplits ? s_list[sp] : slist[sp]) : sp; };
+    auto gslot = [&](int e) -> int { return LISTED ? gsplit(e / kCols) * kCols + (e % kCols) : e; };
+    const int nloc = LISTED ? nact * kCols : nslots; // slots this row looks at
     const float *mine = slotmin + (size_t)local * nslots;
     const int kk = k < 64 ? k : 64;
     const double kInf = 1.7976931348623157e308;
@@ -958,18 +1066,18 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     // kernel's HBM traffic: read them once).
     float sv[kKnnRegSlots];
     float lmin = kBig;
-    int lslot = lane < nslots ? lane : 0;
+    int lslot = lane < nloc ? lane : 0; // LOCAL slot number
 #pragma unroll
     for (int u = 0; u < kKnnRegSlots; ++u) {
         const int e = lane + 64 * u;
-        sv[u] = e < nslots ? mine[e] : kBig;
+        sv[u] = e < nloc ? mine[gslot(e)] : kBig;
         if (sv[u] < lmin) {
             lmin = sv[u];
             lslot = e;
         }
     }
-    for (int e = lane + 64 * kKnnRegSlots; e < nslots; e += 64) {
-        const float v = mine[e];
+    for (int e = lane + 64 * kKnnRegSlots; e < nloc; e += 64) {
+        const float v = mine[gslot(e)];
         if (v < lmin) {
             lmin = v;
             lslot = e;
@@ -999,7 +1107,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     double dloc[kBnd];
     int oloc[kBnd];
     {
-        const int j0 = (bslot / kCols) * kSplitTargets + (bslot % kCols) * kSlotTargets;
+        const int gb = gslot(bslot), j0 = (gb / kCols) * kSplitTargets + (gb % kCols) * kSlotTargets;
 #pragma unroll
         for (int c = 0; c < kBnd; ++c) {
             const int jj = j0 + 64 * c + lane;
@@ -1018,7 +1126,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
 #define ICPMI_KNN_MORE_RUNS 1 /* measured on C3: 0 -> 668 us, 1 -> 555, 2 -> 564, 4 -> 588 */
 #endif
     { // further runs of 64 sorted neighbours on both sides, for the bound only
-        const int j0 = (bslot / kCols) * kSplitTargets + (bslot % kCols) * kSlotTargets;
+        const int gb = gslot(bslot), j0 = (gb / kCols) * kSplitTargets + (gb % kCols) * kSlotTargets;
 #pragma unroll
         for (int c = 0; c < ICPMI_KNN_MORE_RUNS; ++c) {
             const int ja = j0 - 64 * (c + 1) + lane, jb = j0 + 64 * (kBnd + c) + lane;
@@ -1040,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         const float tS = __shfl(wave_sort_asc(lmin, lane), kk - 1, 64);
         double a;
         {
-            const SplitFrame &f = frames[lslot / kCols];
+            const SplitFrame &f = frames[gsplit(lslot / kCols)];
             const double dx = px - f.c[0], dy = py - f.c[1], dz = pz - f.c[2];
             a = lmin <= tS ? sqrt((dx * dx + dy * dy) + dz * dz) * (1.0 + 1e-6) + f.rho : 0.0;
 #pragma unroll
@@ -1061,13 +1169,13 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     // candidates: the best slot's targets under T, then every other slot under its split's
     // bound.  If more than kKnnCap turn up, the k-th smallest of those already held is a
     // tighter valid bound: collect again with it (a few rows per cloud).
-    const int nsplits = (nslots + kCols - 1) / kCols;
+    const int nsplits = LISTED ? nact : (nslots + kCols - 1) / kCols; // (local) splits this row looks at
     static_assert(kSlotTargets <= kKnnCap, "the best slot's targets must fit the candidate list");
     int total = 0;
     for (int attempt = 0; attempt < 4; ++attempt) {
         const double sq = sqrt(T);
         for (int sp = lane; sp < nsplits && sp < kKnnMaxSplits; sp += 64)
-            tau_sp[wave][sp] = T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[sp], T, sq);
+            tau_sp[wave][sp] = T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[gsplit(sp)], T, sq);
         __builtin_amdgcn_wave_barrier();
         total = 0;
 #pragma unroll
@@ -1086,30 +1194,30 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
 #pragma unroll
         for (int u = 0; u < kKnnRegSlots; ++u) {
             const int e = lane + 64 * u;
-            if (e < nslots && e != bslot) {
+            if (e < nloc && e != bslot) {
                 const int sp = e / kCols;
                 const float tauf = sp < kKnnMaxSplits ? tau_sp[wave][sp]
-                                                      : (T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[sp], T, sq));
+                                                      : (T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[gsplit(sp)], T, sq));
                 regflags |= sv[u] <= tauf ? (1u << u) : 0u;
             }
         }
 #pragma unroll 1
-        for (int e0 = 0, u = 0; e0 < nslots; e0 += 64, ++u) {
+        for (int e0 = 0, u = 0; e0 < nloc; e0 += 64, ++u) {
             const int e = e0 + lane;
             bool flag = false;
             if (u < kKnnRegSlots) {
                 flag = (regflags >> u) & 1u;
-            } else if (e < nslots && e != bslot) {
+            } else if (e < nloc && e != bslot) {
                 const int sp = e / kCols;
                 const float tauf = sp < kKnnMaxSplits ? tau_sp[wave][sp]
-                                                      : (T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[sp], T, sq));
-                flag = mine[e] <= tauf;
+                                                      : (T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[gsplit(sp)], T, sq));
+                flag = mine[gslot(e)] <= tauf;
             }
             unsigned long long pend = __ballot(flag);
             while (pend) {
                 const int L = __ffsll((long long)pend) - 1;
                 pend &= pend - 1;
-                const int se = e0 + L;
+                const int se = gslot(e0 + L);
                 const int j0 = (se / kCols) * kSplitTargets + (se % kCols) * kSlotTargets;
 #pragma unroll
                 for (int o = 0; o < kSlotTargets; o += 64) {
@@ -1190,13 +1298,28 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     }
 }
 
+// out[perm[i]] = in[i], rows of 3 doubles (normals gathered in sorted order -> point order)
+__global__ __launch_bounds__(256) void k_scatter_rows(const double *__restrict__ in, const unsigned *__restrict__ perm,
+                                                      int m, double *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const size_t o = perm[i];
+    out[3 * o] = in[3 * i];
+    out[3 * o + 1] = in[3 * i + 1];
+    out[3 * o + 2] = in[3 * i + 2];
+}
+
 // Exact fp64 k-NN list of ONE row per workgroup (rows the MFMA resolve hands back): every
 // thread keeps the k best of its strided share of the targets (sorted, in LDS), then the k
 // global best are popped by k rounds of a workgroup-wide argmin over the list heads.
+// With `perm` the listed rows are sorted positions (pruned engine): row r is point perm[r] and its
+// list is stored at r.
 __global__ __launch_bounds__(256) void k_knn_exact_rows(const double *__restrict__ pts, int m, int k,
                                                         const int *__restrict__ list,
                                                         const int *__restrict__ list_count,
-                                                        int *__restrict__ knn_idx)
+                                                        int *__restrict__ knn_idx,
+                                                        const unsigned *__restrict__ perm)
 {
     extern __shared__ double knn_smem[];
     constexpr int BLOCK = 256;
@@ -1208,7 +1331,8 @@ __global__ __launch_bounds__(256) void k_knn_exact_rows(const double *__restrict
     const int nrows = *list_count;
     for (int lr = blockIdx.x; lr < nrows; lr += gridDim.x) { // block-uniform
         const int i = list[lr];
-        const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+        const size_t ip = perm ? perm[i] : (unsigned)i;
+        const double px = pts[3 * ip], py = pts[3 * ip + 1], pz = pts[3 * ip + 2];
         int cnt = 0;
         double thr = __builtin_inf();
         for (int j = tid; j < m; j += BLOCK) {
@@ -1311,20 +1435,24 @@ __global__ __launch_bounds__(BLOCK) void k_knn_exact_list(const double *__restri
 }
 
 // PCA normal from a closest-first neighbour list (icp.hpp:34-63), one row per thread
+// With `perm`, rows are sorted positions (pruned engine): the list of row i is that of point
+// perm[i]; `scatter` writes its normal where that point lives, normals[perm[i]].
 __global__ __launch_bounds__(256) void k_normals_from_knn(const double *__restrict__ pts, int m, int k,
                                                           int row0, int row1,
                                                           const int *__restrict__ knn_idx,
-                                                          double *__restrict__ normals)
+                                                          double *__restrict__ normals,
+                                                          const unsigned *__restrict__ perm, int scatter)
 {
     const int i = row0 + blockIdx.x * 256 + threadIdx.x;
     if (i >= row1) return;
+    const int self = perm ? (int)perm[i] : i;
     const int cnt = k < m ? k : m;
     const int *nb = knn_idx + (size_t)i * k;
     double nx = 0.0, ny = 0.0, nz = 1.0; // icp.hpp:34-37
     if (cnt >= 3) {
         double cx = 0.0, cy = 0.0, cz = 0.0; // icp.hpp:40-44
         for (int a = 0; a < cnt; ++a) {
-            const int j = (unsigned)nb[a] < (unsigned)m ? nb[a] : i; // rows with NaN coordinates have no list
+            const int j = (unsigned)nb[a] < (unsigned)m ? nb[a] : self; // rows with NaN coordinates have no list
             cx += pts[3 * j];
             cy += pts[3 * j + 1];
             cz += pts[3 * j + 2];
@@ -1335,7 +1463,7 @@ __global__ __launch_bounds__(256) void k_normals_from_knn(const double *__restri
         cz /= kd;
         double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0; // icp.hpp:47-52
         for (int a = 0; a < cnt; ++a) {
-            const int j = (unsigned)nb[a] < (unsigned)m ? nb[a] : i;
+            const int j = (unsigned)nb[a] < (unsigned)m ? nb[a] : self;
             const double dx = pts[3 * j] - cx, dy = pts[3 * j + 1] - cy, dz = pts[3 * j + 2] - cz;
             c00 += dx * dx;
             c01 += dx * dy;
@@ -1363,9 +1491,10 @@ __global__ __launch_bounds__(256) void k_normals_from_knn(const double *__restri
         ny = v[1];
         nz = v[2];
     }
-    normals[3 * i] = nx;
-    normals[3 * i + 1] = ny;
-    normals[3 * i + 2] = nz;
+    const size_t o = scatter ? (size_t)self : (size_t)i; // by point, or by (sorted) row for the all-gather
+    normals[3 * o] = nx;
+    normals[3 * o + 1] = ny;
+    normals[3 * o + 2] = nz;
 }
 
 } // namespace icpmi
