@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, npts=3001):
+def _worker(rank, world, port, out_dir, npts=3001, search=0):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from lidar_slam_from_scratch_amd import capi, dist as icpdist, synth
@@ -31,7 +31,7 @@ def _worker(rank, world, port, out_dir, npts=3001):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     src, tgt, _ = synth.c1_room_corner(npts)
     lo, hi = icpdist.shard_bounds(src.shape[0], world, rank)
-    ctx = capi.Context(device=0)
+    ctx = capi.Context(device=0, search=search)
     icpdist.init_callbacks(ctx, dist)
     res, hist = ctx.align(src[lo:hi], tgt, capi.Context.make_config())
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), T=np.array(res.transformation[:]).reshape(4, 4),
@@ -45,8 +45,13 @@ def _worker(rank, world, port, out_dir, npts=3001):
 @pytest.mark.parametrize("world,npts", [(2, 3001), (3, 3001), (2, 12001)])
 def test_sharded_align_on_one_gpu(tmp_path, oracle, gpu_ctx, world, npts):
     """npts = 12001 is past the size where AUTO picks the MFMA engine, so the sharded path
-    also covers the Morton pre-pass, row-sliced MFMA normals and their all-gather."""
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), npts), nprocs=world, join=True)
+    also covers the Morton pre-pass, row-sliced MFMA normals and their all-gather -- and, with
+    the pruned engine, slices of SORTED rows gathered and scattered back to point order."""
+    from lidar_slam_from_scratch_amd import capi
+    # exact_f64 context -> AUTO in the workers (MFMA engine from 8192 points), the others forced
+    search = {"exact_f64": capi.SEARCH_AUTO, "mfma_bf16": capi.SEARCH_MFMA_BF16,
+              "mfma_pruned": capi.SEARCH_MFMA_PRUNED}[gpu_ctx.engine]
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), npts, search), nprocs=world, join=True)
     r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(world)]
     for k in range(1, world):
         assert (r[0]["T"] == r[k]["T"]).all() and (r[0]["hist"] == r[k]["hist"]).all()
@@ -62,17 +67,18 @@ def test_sharded_align_on_one_gpu(tmp_path, oracle, gpu_ctx, world, npts):
     np.testing.assert_allclose(np.array(single.transformation[:]).reshape(4, 4), r[0]["T"], atol=1e-12)
 
 
-def test_rccl_single_rank_communicator(oracle):
+@pytest.mark.parametrize("search", [0, 3], ids=["auto", "mfma_pruned"])
+def test_rccl_single_rank_communicator(oracle, search):
     """The RCCL plumbing on real hardware (dlopen, unique id, ncclCommInitRank, in-place
     all-gather of the normals, 29-double all-reduce on the library's stream) with a 1-rank
     communicator: the sharded code path must reproduce the plain single-GPU result."""
     from lidar_slam_from_scratch_amd import capi, synth
     src, tgt, _ = synth.c3_uniform(12000, seed=41, perm_seed=42)
     cfg = capi.Context.make_config(6, 0.0, 0.0)
-    plain = capi.Context(device=0)
+    plain = capi.Context(device=0, search=search)
     r0, h0 = plain.align(src, tgt, cfg)
     plain.close()
-    ctx = capi.Context(device=0)
+    ctx = capi.Context(device=0, search=search)
     ctx.comm_init(1, 0, ctx.comm_unique_id())
     r1, h1 = ctx.align(src, tgt, cfg)
     ctx.comm_finalize()
