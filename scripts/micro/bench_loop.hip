@@ -7,7 +7,7 @@
 using namespace icpmi;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
-template <int VAR, int QT, int WAVES, int PADKB = 0>
+template <int VAR, int QT, int WAVES, int PADKB = 0, int KOFF = 0>
 __global__ __launch_bounds__(64 * WAVES) void k_loop(const float4 *__restrict__ Bpack, float *out, int nevertrue)
 {
     constexpr int THREADS = 64 * WAVES;
@@ -262,6 +262,86 @@ __global__ __launch_bounds__(64 * WAVES) void k_loop(const float4 *__restrict__ 
         }
         for (int t = 0; t < QT; ++t) for (int r = 0; r < 16; ++r) keep += mm[t][r];
     }
+    else if (VAR == 12) { // bf16 32x32x16, one MFMA per tile; KOFF of the 16 result registers are
+                          // min-reduced by the LDS (ds_min_f32, no return) instead of the VALU
+        typedef short bf16x8 __attribute__((ext_vector_type(8)));
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        __shared__ float ldsM[(KOFF > 0 ? KOFF : 1) * QT * WAVES * 64];
+        const int wave = threadIdx.x >> 6;
+        bf16x8 alo[QT];
+        for (int t = 0; t < QT; ++t) for (int e = 0; e < 8; ++e) alo[t][e] = (short)(0x3f80 + lane + t + e);
+        f32x16 mm[QT];
+        for (int t = 0; t < QT; ++t) for (int r = 0; r < 16; ++r) mm[t][r] = kBig;
+        for (int e = 0; e < KOFF * QT; ++e) ldsM[(e * WAVES + wave) * 64 + lane] = kBig;
+        f32x16 z16;
+        for (int r = 0; r < 16; ++r) z16[r] = 0.f;
+        const bf16x8 *ldsH = reinterpret_cast<const bf16x8 *>(ldsB);
+#pragma unroll 1
+        for (int tt = 0; tt < 64; tt += 2) {
+            const bf16x8 b0 = ldsH[(tt & 31) * 64 + lane], b1 = ldsH[((tt + 1) & 31) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const f32x16 da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], b0, z16, 0, 0, 0);
+                const f32x16 db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], b1, z16, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16 - KOFF; ++r) mm[t][r] = min3f(mm[t][r], da[r], db[r]);
+#pragma unroll
+                for (int r = 0; r < KOFF; ++r) {
+                    float *slot = &ldsM[((t * KOFF + r) * WAVES + wave) * 64 + lane];
+                    (void)__hip_atomic_fetch_min(slot, da[16 - KOFF + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_min(slot, db[16 - KOFF + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        for (int t = 0; t < QT; ++t) for (int r = 0; r < 16 - KOFF; ++r) keep += mm[t][r];
+        for (int e = 0; e < KOFF * QT; ++e) keep += ldsM[(e * WAVES + wave) * 64 + lane];
+    }
+    else if (VAR == 13) { // as 10 with 2-input minima in a tree: t = min(da, db); m = min(m, t)
+        typedef short bf16x8 __attribute__((ext_vector_type(8)));
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        bf16x8 alo[QT];
+        for (int t = 0; t < QT; ++t) for (int e = 0; e < 8; ++e) alo[t][e] = (short)(0x3f80 + lane + t + e);
+        f32x16 mm[QT];
+        for (int t = 0; t < QT; ++t) for (int r = 0; r < 16; ++r) mm[t][r] = kBig;
+        f32x16 z16;
+        for (int r = 0; r < 16; ++r) z16[r] = 0.f;
+        const bf16x8 *ldsH = reinterpret_cast<const bf16x8 *>(ldsB);
+#pragma unroll 1
+        for (int tt = 0; tt < 64; tt += 2) {
+            const bf16x8 b0 = ldsH[(tt & 31) * 64 + lane], b1 = ldsH[((tt + 1) & 31) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const f32x16 da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], b0, z16, 0, 0, 0);
+                const f32x16 db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], b1, z16, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float x = __builtin_fminf(da[r], db[r]);
+                    asm volatile("" : "+v"(x)); // keep it a 2-input min (no min3 fusion)
+                    mm[t][r] = __builtin_fminf(mm[t][r], x);
+                }
+            }
+        }
+        for (int t = 0; t < QT; ++t) for (int r = 0; r < 16; ++r) keep += mm[t][r];
+    }
+    else if (VAR == 14) { // MFMA only: results folded by accumulation in the matrix core (no VALU in the loop)
+        typedef short bf16x8 __attribute__((ext_vector_type(8)));
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        bf16x8 alo[QT];
+        for (int t = 0; t < QT; ++t) for (int e = 0; e < 8; ++e) alo[t][e] = (short)(0x3f80 + lane + t + e);
+        f32x16 mm[QT];
+        for (int t = 0; t < QT; ++t) for (int r = 0; r < 16; ++r) mm[t][r] = 0.f;
+        const bf16x8 *ldsH = reinterpret_cast<const bf16x8 *>(ldsB);
+#pragma unroll 1
+        for (int tt = 0; tt < 64; tt += 2) {
+            const bf16x8 b0 = ldsH[(tt & 31) * 64 + lane], b1 = ldsH[((tt + 1) & 31) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                mm[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], b0, mm[t], 0, 0, 0);
+                mm[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[t], b1, mm[t], 0, 0, 0);
+            }
+        }
+        for (int t = 0; t < QT; ++t) for (int r = 0; r < 16; ++r) keep += mm[t][r];
+    }
     float acc = keep;
     for (int t = 0; t < QT; ++t) for (int r = 0; r < 4; ++r) acc += m[t][r];
     if (acc == (float)nevertrue) out[threadIdx.x] = acc;
@@ -295,7 +375,8 @@ int main()
 #define RUN(VAR, QT, W) { const int qpb = 16 * QT * W; float ms = timeit([&] { hipLaunchKernelGGL((k_loop<VAR, QT, W>), dim3((n + qpb - 1) / qpb, splits), dim3(64 * W), 0, 0, bp, out, -12345); }); printf("var %d QT=%d W=%d : %.3f ms  (%.1f%%)\n", VAR, QT, W, ms, 100 * ideal_ms / ms); }
 #define RUN32(VAR, QT, W) { const int qpb = 32 * QT * W; float ms = timeit([&] { hipLaunchKernelGGL((k_loop<VAR, QT, W>), dim3((n + qpb - 1) / qpb, splits), dim3(64 * W), 0, 0, bp, out, -12345); }); printf("var %d QT32=%d W=%d : %.3f ms  (%.1f%%)\n", VAR, QT, W, ms, 100 * ideal_ms / ms); }
 #define RUNP(VAR, QT, W, PAD) { const int qpb = 32 * QT * W; float ms = timeit([&] { hipLaunchKernelGGL((k_loop<VAR, QT, W, PAD>), dim3((n + qpb - 1) / qpb, splits), dim3(64 * W), 0, 0, bp, out, -12345); }); printf("var %d QT32=%d W=%d padKB=%d : %.3f ms  (%.1f%%)\n", VAR, QT, W, PAD, ms, 100 * ideal_ms / ms); }
-    RUNP(10, 2, 4, 100) RUNP(11, 2, 4, 100) RUNP(11, 4, 4, 100) RUNP(10, 4, 4, 100) RUNP(11, 2, 8, 100) RUNP(11, 4, 8, 100) RUNP(11, 2, 4, 40) RUNP(11, 4, 4, 40)
-    RUN(6, 4, 8) RUN(6, 8, 8) RUN32(10, 2, 8) RUN32(11, 2, 8) RUN32(10, 4, 8) RUN32(11, 4, 8) RUN32(10, 2, 4) RUN32(11, 2, 4) RUN32(10, 1, 8)
+#define RUNK(VAR, QT, W, K) { const int qpb = 32 * QT * W; float ms = timeit([&] { hipLaunchKernelGGL((k_loop<VAR, QT, W, 0, K>), dim3((n + qpb - 1) / qpb, splits), dim3(64 * W), 0, 0, bp, out, -12345); }); printf("var %d QT32=%d W=%d KOFF=%d : %.3f ms  (%.1f%%)\n", VAR, QT, W, K, ms, 100 * ideal_ms / ms); }
+    RUN32(10, 2, 8) RUN32(13, 2, 8) RUN32(14, 2, 8)
+    RUNK(12, 2, 8, 0) RUNK(12, 2, 8, 1) RUNK(12, 2, 8, 2) RUNK(12, 2, 8, 3) RUNK(12, 2, 8, 4) RUNK(12, 2, 8, 6) RUNK(12, 2, 8, 8)
     return 0;
 }
