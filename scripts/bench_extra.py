@@ -10,6 +10,7 @@ from oracle import oracle as orc
 
 out = {}
 ctx = capi.Context(device=0, profile=1)
+pctx = capi.Context(device=0, search=capi.SEARCH_MFMA_PRUNED, profile=1)   # opt-in engine, same jobs
 
 # C2 stand-in: LiDAR-like pair, ~20k points, reference defaults (50 it, tol 1e-6)
 src, tgt, T = synth.c2_lidar_pair()
@@ -18,7 +19,10 @@ ctx.align(src, tgt, cfg)
 t0 = time.perf_counter(); res, hist = ctx.align(src, tgt, cfg); g = time.perf_counter() - t0
 t0 = time.perf_counter(); ref = orc.icp_point_to_plane(src, tgt); c = time.perf_counter() - t0
 dt, dr = synth.pose_delta(np.array(res.transformation[:]).reshape(4, 4), ref.transformation)
+pctx.align(src, tgt, cfg)
+t0 = time.perf_counter(); pres, _ = pctx.align(src, tgt, cfg); gp = time.perf_counter() - t0
 out["c2_lidar_pair"] = {"n_src": int(src.shape[0]), "n_tgt": int(tgt.shape[0]), "gpu_call_ms": 1e3 * g,
+                        "gpu_call_ms_pruned_engine": 1e3 * gp, "pruned_iterations": pres.num_iterations,
                         "cpu_call_ms": 1e3 * c, "iterations": res.num_iterations, "pose_dt": dt, "pose_dr": dr,
                         "iters_equal": res.num_iterations == ref.num_iterations}
 
@@ -27,11 +31,15 @@ frames = [synth.lidar_frame(f) for f in range(12)]
 truth = [synth.lidar_pose(f) for f in range(12)]
 odometry.run_odometry(frames[:3], odometry.gpu_align(ctx))
 t0 = time.perf_counter(); tr = odometry.run_odometry(frames, odometry.gpu_align(ctx)); g = time.perf_counter() - t0
+odometry.run_odometry(frames[:3], odometry.gpu_align(pctx))
+t0 = time.perf_counter(); trp = odometry.run_odometry(frames, odometry.gpu_align(pctx)); gp = time.perf_counter() - t0
 t0 = time.perf_counter()
 rf = odometry.run_odometry(frames, lambda s, t, mi, tol: orc.icp_point_to_plane(s, t, mi, tol, 1e-9))
 c = time.perf_counter() - t0
 out["c5_odometry_12_frames"] = {"points_per_frame": int(np.mean([f.shape[0] for f in frames])),
                                 "gpu_ms_per_frame": 1e3 * g / 11, "cpu_ms_per_frame": 1e3 * c / 11,
+                                "gpu_ms_per_frame_pruned_engine": 1e3 * gp / 11,
+                                "pruned_iterations_equal": trp.iterations == rf.iterations,
                                 "ate_gpu_m": odometry.absolute_trajectory_error(tr, truth),
                                 "ate_cpu_m": odometry.absolute_trajectory_error(rf, truth),
                                 "iterations_equal": tr.iterations == rf.iterations}
@@ -42,10 +50,14 @@ if "--c4" in sys.argv:
     cfg = capi.Context.make_config(3, 0.0, 0.0)
     t0 = time.perf_counter(); res, hist = ctx.align(src, tgt, cfg); g = time.perf_counter() - t0
     p = ctx.get_profile()
+    pctx.align(src[:200000], tgt, cfg)  # warm the workspaces
+    t0 = time.perf_counter(); pres, phist = pctx.align(src, tgt, cfg); gp = time.perf_counter() - t0
     nth = os.cpu_count() or 8
     t0 = time.perf_counter(); ref = orc.icp_point_to_plane(src, tgt, 3, 0.0, 0.0, faithful=False, nthreads=nth); c = time.perf_counter() - t0
     dt, dr = synth.pose_delta(np.array(res.transformation[:]).reshape(4, 4), ref.transformation)
-    out["c4_1M_3_iterations"] = {"gpu_call_s": g, "cpu_call_s_%d_threads" % nth: c, "pose_dt": dt, "pose_dr": dr,
+    out["c4_1M_3_iterations"] = {"gpu_call_s": g, "gpu_call_s_pruned_engine": gp,
+                                 "pruned_hist_max_abs_diff": float(np.abs(phist - ref.error_history).max()),
+                                 "cpu_call_s_%d_threads" % nth: c, "pose_dt": dt, "pose_dr": dr,
                                  "hist_max_abs_diff": float(np.abs(hist - ref.error_history).max()),
                                  "coarse_ms_per_pass": p["coarse_ms"] / max(p["coarse_launches"], 1)}
 print(json.dumps(out, indent=1))
