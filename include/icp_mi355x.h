@@ -95,7 +95,8 @@ typedef struct {
     int64_t nn_pruned_blocks;                        /* of those, skipped by ICPMI_SEARCH_MFMA_PRUNED's box test */
 } icpmi_profile;
 
-void icpmi_options_default(icpmi_options *opt);
+void icpmi_options_default(icpmi_options *opt);     /* device 0, normal_k 20 (icp.hpp:170), search AUTO or the
+                                                        value of the environment variable ICPMI_SEARCH (0..3) */
 void icpmi_config_default(icpmi_config *cfg);        /* types.hpp:143-148 defaults */
 
 int icpmi_create(const icpmi_options *opt, icpmi_ctx **out);

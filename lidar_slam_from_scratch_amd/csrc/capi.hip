@@ -800,6 +800,13 @@ void icpmi_options_default(icpmi_options *opt)
     opt->normal_k = 20; // icp.hpp:170
     opt->search = ICPMI_SEARCH_AUTO;
     opt->profile = 0;
+    // a drop-in caller (slam_icp_adapter.hpp) never sees the options: let the environment pick
+    // the engine.  Values outside 0..3 are ignored.
+    if (const char *e = getenv("ICPMI_SEARCH")) {
+        char *end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end != e && *end == '\0' && v >= ICPMI_SEARCH_AUTO && v <= ICPMI_SEARCH_MFMA_PRUNED) opt->search = (int32_t)v;
+    }
 }
 
 void icpmi_config_default(icpmi_config *cfg)

@@ -46,6 +46,19 @@ def test_struct_layouts_match_header(lib):
     assert opt.normal_k == 20  # icp.hpp:170
 
 
+def test_search_engine_can_be_chosen_from_the_environment(lib, monkeypatch):
+    """A drop-in caller (slam_icp_adapter.hpp) never sees icpmi_options: ICPMI_SEARCH does."""
+    opt = capi.Options()
+    monkeypatch.delenv("ICPMI_SEARCH", raising=False)
+    lib.icpmi_options_default(ctypes.byref(opt))
+    assert opt.search == capi.SEARCH_AUTO
+    for text, want in (("3", capi.SEARCH_MFMA_PRUNED), ("1", capi.SEARCH_EXACT_F64), ("7", capi.SEARCH_AUTO),
+                       ("-1", capi.SEARCH_AUTO), ("pruned", capi.SEARCH_AUTO), ("", capi.SEARCH_AUTO)):
+        monkeypatch.setenv("ICPMI_SEARCH", text)
+        lib.icpmi_options_default(ctypes.byref(opt))
+        assert opt.search == want, text
+
+
 def test_library_carries_gfx950_code_only():
     """Every device code object bundled in the library targets gfx950 (rocPRIM's host-side
     arch-name table also mentions other gfx names; those are strings, not code)."""
