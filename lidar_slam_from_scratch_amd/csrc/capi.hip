@@ -270,7 +270,25 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
 
 // when d_nrm/d_partials are given the resolve kernel also does k_reduce's work (one partial
 // row per resolve workgroup: resolve_blocks(n) rows)
-int resolve_blocks(int n) { return (n + 4 * kResolveQ - 1) / (4 * kResolveQ); }
+// Which resolve kernel: 0 = k_nn_resolve (16 queries per wave, 64 per workgroup); W > 0 =
+// k_nn_resolve4<W> (4 queries per wave, 4 W per workgroup).  Build-time override for A/B runs.
+#ifndef ICPMI_RESOLVE_WAVES
+#define ICPMI_RESOLVE_WAVES -1
+#endif
+int resolve_waves(int n)
+{
+    if (ICPMI_RESOLVE_WAVES >= 0) return ICPMI_RESOLVE_WAVES;
+    // measured (scripts/sweep_resolve*.sh, resolve + finish_step per pass, 100k targets): 8.8k / 12.5k /
+    // 25k queries 34 -> 25 / 37 -> 27 / 41 -> 36 us with the quarter-wave kernel, 50k / 100k queries
+    // 46 -> 52 / 63 -> 80 us (its 2-4x more partial rows and waves cost more than the shorter chains save)
+    return n <= 32768 ? 8 : 0;
+}
+int resolve_blocks(int n)
+{
+    const int w = resolve_waves(n);
+    const int per = w ? 4 * w : 4 * kResolveQ;
+    return (n + per - 1) / per;
+}
 
 int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx, double *d_d2,
                    const IcpState *st, const double *d_tgt = nullptr, const double *d_nrm = nullptr,
@@ -303,9 +321,16 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     }
     const int *blk_cnt = pruned_pass >= 0 ? (const int *)ctx->blk_lists.p : nullptr;
     const int *blk_list = blk_cnt ? blk_cnt + (n + kCoarseQueries - 1) / kCoarseQueries : nullptr;
-    hipLaunchKernelGGL(k_nn_resolve, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream,
-                       d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits,
-                       frames, d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, blk_cnt, blk_list, st);
+#define ICPMI_RESOLVE_ARGS                                                                                            \
+    d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits, frames,  \
+        d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, blk_cnt, blk_list, st
+    switch (resolve_waves(n)) {
+    case 0: hipLaunchKernelGGL(k_nn_resolve, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
+    case 4: hipLaunchKernelGGL(k_nn_resolve4<4>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
+    case 8: hipLaunchKernelGGL(k_nn_resolve4<8>, dim3(resolve_blocks(n)), dim3(512), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
+    default: hipLaunchKernelGGL(k_nn_resolve4<16>, dim3(resolve_blocks(n)), dim3(1024), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
+    }
+#undef ICPMI_RESOLVE_ARGS
     ctx->prof.nn_pairs += (double)n * (double)m;
     HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;

@@ -975,6 +975,192 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
     }
 }
 
+// Variant with one query per QUARTER-wave (4 queries per wave): the 16 lanes of a quarter share
+// the splits of their query (lane ql takes list entries ql, ql+16, ...) and scan its winning
+// slot together, in one round.  Same result as k_nn_resolve; a wave's chain of dependent memory
+// round trips is ~4x shorter, which is what matters when there is about one wave per SIMD or
+// less (clouds of ~10k points, one shard of a multi-GPU job, the pruned engine).
+// One partial row of normal-equation terms per workgroup = per 4*WAVES queries.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__restrict__ qry, int n,
+                                                           const double *__restrict__ sorted,
+                                                           const unsigned *__restrict__ perm, int m, int ms,
+                                                           const float2 *__restrict__ coarse, int splits,
+                                                           const SplitFrame *__restrict__ frames,
+                                                           int *__restrict__ idx, double *__restrict__ d2out,
+                                                           unsigned long long *__restrict__ counters,
+                                                           const double *__restrict__ tgt_orig,
+                                                           const double *__restrict__ nrm,
+                                                           double *__restrict__ partials,
+                                                           const int *__restrict__ blk_cnt,
+                                                           const int *__restrict__ blk_list,
+                                                           const IcpState *__restrict__ st)
+{
+    if (st && st->done) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 15, quarter = lane >> 4;
+    const int qbase = (blockIdx.x * WAVES + wave) * 4;
+    const int i = qbase + quarter; // waves past the end run on a clamped query and write nothing
+    const bool valid = i < n;
+    const int ic = valid ? i : n - 1;
+    const double px = qry[3 * ic], py = qry[3 * ic + 1], pz = qry[3 * ic + 2];
+    static_assert(kCoarseQueries % 4 == 0, "a wave's queries share a coarse block");
+    const int *slist = blk_list ? blk_list + (size_t)(qbase / kCoarseQueries) * splits : nullptr;
+    const int nact = blk_list ? (qbase < n ? blk_cnt[qbase / kCoarseQueries] : 0) : splits;
+
+    // phase 1: smallest coarse value over the splits; ties to the lowest split
+    float best = kBig;
+    int bs = 0;
+    for (int e = ql; e < nact; e += 16) {
+        const int s = slist ? slist[e] : e;
+        const float v = coarse[(size_t)s * n + ic].x;
+        if (v < best || (v == best && s < bs)) {
+            best = v;
+            bs = s;
+        }
+    }
+#pragma unroll
+    for (int x = 1; x < 16; x <<= 1) {
+        const float ov = __shfl_xor(best, x, 64);
+        const int os = __shfl_xor(bs, x, 64);
+        if (ov < best || (ov == best && os < bs)) {
+            best = ov;
+            bs = os;
+        }
+    }
+    const int bcol = (int)(__float_as_uint(best) & 31u);
+
+    // phase 2: exact evaluation of the winning slot by the quarter (lane ql: positions ql, ql+16, ...)
+    double bd = 1.7976931348623157e308;
+    int bj = 0x7fffffff;
+    {
+        const int j0 = bs * kSplitTargets + bcol * kSlotTargets + ql;
+#pragma unroll
+        for (int o = 0; o < kSlotTargets / 16; ++o) {
+            const int jj = j0 + 16 * o;
+            const int jc = jj < m ? jj : m - 1;
+            const double dd = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), px, py, pz);
+            const int oj = (int)perm[jc];
+            if (jj < m && (dd < bd || (dd == bd && oj < bj))) {
+                bd = dd;
+                bj = oj;
+            }
+        }
+#pragma unroll
+        for (int x = 1; x < 16; x <<= 1) {
+            const double od = __shfl_xor(bd, x, 64);
+            const int oj = __shfl_xor(bj, x, 64);
+            if (od < bd || (od == bd && oj < bj)) {
+                bd = od;
+                bj = oj;
+            }
+        }
+    }
+
+    // phase 3: certificate, split by split (tau depends on the split's frame)
+    const double sq = sqrt(bd);
+    unsigned extra_slots = 0, extra_splits = 0;
+    int nact_max = nact; // wave-uniform already (one block per wave)
+    for (int e0 = 0; e0 < nact_max; e0 += 16) {
+        const int e = e0 + ql;
+        int s = 0;
+        bool whole = false, slot = false;
+        float2 v = make_float2(kBig, kBig);
+        if (e < nact && valid) {
+            s = slist ? slist[e] : e;
+            v = coarse[(size_t)s * n + ic];
+            const float tauf = split_tau(px, py, pz, frames[s], bd, sq);
+            whole = v.y <= tauf;                       // a second column is inside the bound
+            slot = !whole && s != bs && v.x <= tauf;
+        }
+        unsigned long long pend = __ballot(whole || slot);
+        while (pend) {                                 // rare; wave-uniform loop
+            const int L = __ffsll((long long)pend) - 1;
+            pend &= pend - 1;
+            const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
+            const int w = __shfl((int)whole, L, 64);
+            const int c = __shfl((int)(__float_as_uint(v.x) & 31u), L, 64);
+            const int sL = __shfl(s, L, 64);
+            double d = 1.7976931348623157e308;
+            int j = 0x7fffffff;
+            if (w) scan_range(sorted, perm, m, ms, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
+            else scan_range(sorted, perm, m, ms, sL * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
+            if (quarter == (L >> 4)) { // every lane of that query's quarter takes the result
+                if (d < bd || (d == bd && j < bj)) {
+                    bd = d;
+                    bj = j;
+                }
+            }
+            if (lane == L) {
+                if (w) ++extra_splits;
+                else ++extra_slots;
+            }
+        }
+    }
+    if (valid && ql == 0) {
+        idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
+        if (d2out) d2out[i] = bd;
+    }
+    if (counters) {
+        unsigned es = extra_slots, ef = extra_splits;
+        for (int off = 32; off > 0; off >>= 1) {
+            es += __shfl_down(es, off, 64);
+            ef += __shfl_down(ef, off, 64);
+        }
+        if (lane == 0 && (es | ef)) {
+            atomicAdd(&counters[0], (unsigned long long)es);
+            atomicAdd(&counters[1], (unsigned long long)ef);
+        }
+    }
+    // fused residual + normal equations (icp.hpp:99-120,198-206): the 4 owners of a wave (lane 0
+    // of each quarter) form their J row and b; rows -> LDS, each wave sums its four by column,
+    // the waves' sums meet in LDS in wave order: one partial row per workgroup
+    if (partials) {
+        __shared__ double jrow[WAVES * 4][29];
+        __shared__ double red[WAVES][28];
+        if (ql == 0) {
+            double acc[28];
+#pragma unroll
+            for (int e = 0; e < 28; ++e) acc[e] = 0.0;
+            if (valid) {
+                const int j = (unsigned)bj < (unsigned)m ? bj : 0;
+                const double q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
+                const double n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
+                double J[6];
+                J[0] = py * n2 - pz * n1; // p x n, icp.hpp:105
+                J[1] = pz * n0 - px * n2;
+                J[2] = px * n1 - py * n0;
+                J[3] = n0;
+                J[4] = n1;
+                J[5] = n2;
+                const double e0 = q0 - px, e1 = q1 - py, e2 = q2 - pz;
+                const double b = (e0 * n0 + e1 * n1) + e2 * n2; // icp.hpp:116
+                int o = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = r; c < 6; ++c) acc[o++] = J[r] * J[c];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) acc[21 + r] = J[r] * b;
+                acc[27] = b * b;
+            }
+#pragma unroll
+            for (int e = 0; e < 28; ++e) jrow[wave * 4 + quarter][e] = acc[e];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 28)
+            red[wave][lane] = ((jrow[wave * 4][lane] + jrow[wave * 4 + 1][lane]) + jrow[wave * 4 + 2][lane]) + jrow[wave * 4 + 3][lane];
+        __syncthreads();
+        if (threadIdx.x < 28) {
+            const int e = threadIdx.x;
+            double v = red[0][e];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) v += red[w][e];
+            partials[(size_t)blockIdx.x * kSumsStride + e] = v;
+        }
+    }
+}
+
 // ---- k-NN on the same coarse pass ---------------------------------------------------------------
 // Resolve for the k nearest neighbours of point i among all targets (icp.hpp:32,
 // kdtree.hpp:65-78), one wave per row.  Two upper bounds T on the k-th neighbour's exact
