@@ -56,6 +56,7 @@ constexpr int kCols = 32;                         // columns (slots) per split
 #define ICPMI_SPLIT_TILES 64
 #endif
 constexpr int kSplitTiles = ICPMI_SPLIT_TILES;    // target tiles per split (build-time tunable)
+static_assert(kSplitTiles % 64 == 0, "slots (kSplitTiles targets) are scanned in runs of 64; 32 was tried: slower and not supported");
 constexpr int kSplitTargets = kSplitTiles * kTile;// targets per split
 constexpr int kSlotTargets = kSplitTiles;         // targets per (split, column) slot
 constexpr int kChunkTiles = 32;                   // tiles staged in LDS at a time (32 KiB)
