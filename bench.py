@@ -73,8 +73,17 @@ def main():
     ap.add_argument("--no-pruned-extra", action="store_true",
                     help="skip the extra, untimed-by-the-contract run of the opt-in pruned engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal on one GPU: take the multi-rank code path (process group, RCCL communicator "
+                         "inside the library, sharded kernels) with a world of 1")
     ap.add_argument("--cpu-steps", type=int, default=None)
     args = ap.parse_args()
+
+    # stdout carries exactly one line, the JSON: whatever a library prints there (RCCL announces
+    # its version on stdout when a communicator is created) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     from lidar_slam_from_scratch_amd import capi, dist as icpdist, synth
@@ -88,8 +97,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     src, tgt, _T = synth.c3_uniform(args.points)
@@ -99,9 +112,10 @@ def main():
     torch.cuda.synchronize()
 
     # profile level 1: HIP events around the dominant kernel and the call/loop only
-    ctx = capi.Context(device=local_rank, search=args.search, profile=1)
-    if world > 1:
-        icpdist.init_rccl(ctx, dist, device=dev)
+    # (the fp64 engine has no single dominant kernel bracket: time its whole NN pass instead)
+    ctx = capi.Context(device=local_rank, search=args.search, profile=2 if args.search == 1 else 1)
+    if dist is not None:
+        icpdist.init_rccl(ctx, dist, device=dev, allow_single=args.force_dist)
 
     def call(iters):
         cfg = capi.Context.make_config(max_iterations=iters, tolerance=0.0, min_error=0.0)
@@ -127,24 +141,23 @@ def main():
         elapsed = float(t.item())
     prof = ctx.get_profile()
     assert res.loop_iterations == args.steps, (res.loop_iterations, args.steps)
-    # per-stage breakdown from a second, untimed call with every stage bracketed by events
-    ctx.close()
-    ctx = capi.Context(device=local_rank, search=args.search, profile=2)
-    if world > 1:
-        icpdist.init_rccl(ctx, dist, device=dev)
-    call(args.steps)
-    ctx.reset_profile()
-    call(args.steps)
-    stage = ctx.get_profile()
+    # per-stage breakdown from a second, untimed call with every stage bracketed by events.
+    # Single-GPU runs only: the multi-rank line carries nothing that needs a second communicator.
+    stage = None
+    if dist is None:
+        ctx.close()
+        ctx = capi.Context(device=local_rank, search=args.search, profile=2)
+        call(args.steps)
+        ctx.reset_profile()
+        call(args.steps)
+        stage = ctx.get_profile()
 
     # extra: the opt-in pruned engine (ICPMI_SEARCH_MFMA_PRUNED) on the same job, same timing
     # protocol.  Reported beside `value`, never as `value`: it is not an all-pairs pass.
     pruned = None
-    if not args.no_pruned_extra and args.search in (0, 2):
+    if dist is None and not args.no_pruned_extra and args.search in (0, 2):
         ctx.close()
         ctx = capi.Context(device=local_rank, search=capi.SEARCH_MFMA_PRUNED, profile=1)
-        if world > 1:
-            icpdist.init_rccl(ctx, dist, device=dev)
         if args.warmup > 0:
             call(args.warmup)
         ctx.reset_profile()
@@ -172,8 +185,8 @@ def main():
         n_local, m = hi - lo, tgt.shape[0]
         mfma = prof["coarse_launches"] > 0
         # dominant kernel: k_nn_coarse (bf16 MFMA engine) or the whole fp64 pass (exact engine)
-        k_ms = prof["coarse_ms"] / prof["coarse_launches"] if mfma else stage["nn_ms"] / max(stage["nn_launches"], 1)
-        nn_avg_ms = stage["nn_ms"] / max(stage["nn_launches"], 1)
+        k_ms = prof["coarse_ms"] / prof["coarse_launches"] if mfma else prof["nn_ms"] / max(prof["nn_launches"], 1)
+        nn_avg_ms = stage["nn_ms"] / max(stage["nn_launches"], 1) if stage else None
         flops = FLOP_PER_PAIR * n_local * m
         achieved = flops / (k_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if mfma else PEAK_FP32_TFLOPS
@@ -200,13 +213,15 @@ def main():
                                    "1 call incl. 20-NN normals + final pass" % (src.shape[0], m, args.steps),
                        "source_points": int(src.shape[0]), "target_points": int(m),
                        "parallelism": "source sharded x%d, 29-double RCCL all-reduce/iter" % world
-                       if world > 1 else "single GPU",
+                       if dist is not None else "single GPU",
                        "search": "bf16 MFMA coarse pass over all pairs + certified fp64 resolve" if mfma
                        else "exact fp64 brute force"},
             "steady_state_it_per_s": (args.steps + 1) / (prof["loop_ms"] * 1e-3) if prof["loop_ms"] > 0 else None,
             "stage_ms_untimed_call": {k: stage[k] for k in ("nn_ms", "coarse_ms", "reduce_ms", "transform_ms",
-                                                            "normals_ms", "setup_ms", "loop_ms", "total_ms")},
-            "resolve_counters": {k: stage[k] for k in ("nn_recheck_queries", "nn_fallback_queries", "knn_fallback_rows")},
+                                                            "normals_ms", "setup_ms", "loop_ms", "total_ms")}
+            if stage else None,
+            "resolve_counters": {k: stage[k] for k in ("nn_recheck_queries", "nn_fallback_queries", "knn_fallback_rows")}
+            if stage else None,
             "final_error": res.final_error,
             "pruned_engine_extra": pruned,
             "roofline": {
@@ -222,7 +237,7 @@ def main():
                 "achieved_hbm_GBps": algo_bytes / (k_ms * 1e-3) / 1e9,
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and dist is None:
             cb = cpu_baseline(src, tgt, args.cpu_steps or args.steps)
             r = cb.pop("result")
             T = np.array(res.transformation[:]).reshape(4, 4)
@@ -233,7 +248,8 @@ def main():
                                  "final_error_abs_diff": abs(r.final_error - res.final_error)}
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_1thread"] = out["value"] / cb["value"]
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist is not None:
         dist.barrier()

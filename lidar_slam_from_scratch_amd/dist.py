@@ -19,11 +19,13 @@ def shard_bounds(n, n_ranks, rank):
     return lo, hi
 
 
-def init_rccl(ctx, dist, device=None):
-    """Create the library's RCCL communicator over the ranks of torch.distributed."""
+def init_rccl(ctx, dist, device=None, allow_single=False):
+    """Create the library's RCCL communicator over the ranks of torch.distributed.  A world of
+    one needs no exchange and gets none, unless `allow_single` asks for the sharded code path
+    anyway (rehearsal of the multi-GPU run on one GPU)."""
     import torch
     n_ranks, rank = dist.get_world_size(), dist.get_rank()
-    if n_ranks == 1:
+    if n_ranks == 1 and not allow_single:
         return
     ident = [ctx.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(ident, src=0, device=device)
