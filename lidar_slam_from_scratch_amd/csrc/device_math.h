@@ -81,71 +81,114 @@ __device__ inline void smallest_eigvec_sym3(const double c[6], double out[3])
 
 // 6x6 symmetric solve, Eigen-3.4 LDLT semantics: diagonal pivoting on the largest
 // |diagonal| (first maximum), unit-lower L, pseudo-inverse of D with |D_i| <= DBL_MIN
-// mapped to 0.  M is the full symmetric matrix (row-major 36), overwritten.
-// `work` holds 12 doubles (pivot indices and a temporary row); like M it should live in LDS:
-// the pivot swaps index at run time, so private arrays would land in scratch (global memory).
-__device__ inline void ldlt6_solve(double *M, const double *rhs, double *x, double *work)
+// mapped to 0.  Everything stays in registers: the loops are fully unrolled and the run-time
+// pivot row is matched against each candidate p, so every array index is a compile-time
+// constant (a first version kept the matrix in LDS and indexed it at run time: ~300 dependent
+// LDS round trips, most of k_finish_step's time).
+__device__ inline void ldlt6_solve(const double *sums27 /* 21 upper-triangle terms + 6 rhs */, double *xout)
 {
-    double *w = work;
-    double *permf = work + 6; // pivot row of step k, kept as a double
-#define perm(k) permf[k]
-#define A(i, j) M[(i) * 6 + (j)]
+    double A[6][6];
+    {
+        int o = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) {
+                A[r][c] = sums27[o];
+                A[c][r] = sums27[o];
+                ++o;
+            }
+    }
+    int perm[6] = {0, 1, 2, 3, 4, 5};
+    bool bail = false;
+#define ICPMI_SWAP(a, b) do { const double t_ = (a); (a) = (b); (b) = t_; } while (0)
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
-        int piv = k;
-        double best = fabs(A(k, k));
-        for (int i = k + 1; i < 6; ++i) {
-            const double v = fabs(A(i, i));
-            if (v > best) { best = v; piv = i; }
-        }
-        perm(k) = (double)piv;
-        if (piv != k) {
-            // symmetric row/column interchange carried out on the lower triangle
-            for (int j = 0; j < k; ++j) { const double t = A(k, j); A(k, j) = A(piv, j); A(piv, j) = t; }
-            for (int i = piv + 1; i < 6; ++i) { const double t = A(i, k); A(i, k) = A(i, piv); A(i, piv) = t; }
-            { const double t = A(k, k); A(k, k) = A(piv, piv); A(piv, piv) = t; }
-            for (int i = k + 1; i < piv; ++i) { const double t = A(i, k); A(i, k) = A(piv, i); A(piv, i) = t; }
-        }
-        if (k > 0) {
-            double dot = 0.0;
-            for (int j = 0; j < k; ++j) {
-                w[j] = A(j, j) * A(k, j);
-                dot += A(k, j) * w[j];
-            }
-            A(k, k) -= dot;
+        if (!bail) {
+            int piv = k;
+            double best = fabs(A[k][k]);
+#pragma unroll
             for (int i = k + 1; i < 6; ++i) {
-                double s = 0.0;
-                for (int j = 0; j < k; ++j) s += A(i, j) * w[j];
-                A(i, k) -= s;
+                const double v = fabs(A[i][i]);
+                if (v > best) { best = v; piv = i; }
+            }
+            perm[k] = piv;
+#pragma unroll
+            for (int p = k + 1; p < 6; ++p) {
+                if (piv == p) {
+#pragma unroll
+                    for (int j = 0; j < k; ++j) ICPMI_SWAP(A[k][j], A[p][j]);
+#pragma unroll
+                    for (int i = p + 1; i < 6; ++i) ICPMI_SWAP(A[i][k], A[i][p]);
+                    ICPMI_SWAP(A[k][k], A[p][p]);
+#pragma unroll
+                    for (int i = k + 1; i < p; ++i) ICPMI_SWAP(A[i][k], A[p][i]);
+                }
+            }
+            if (k > 0) {
+                double w[6];
+                double dot = 0.0;
+#pragma unroll
+                for (int j = 0; j < k; ++j) {
+                    w[j] = A[j][j] * A[k][j];
+                    dot += A[k][j] * w[j];
+                }
+                A[k][k] -= dot;
+#pragma unroll
+                for (int i = k + 1; i < 6; ++i) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < k; ++j) sacc += A[i][j] * w[j];
+                    A[i][k] -= sacc;
+                }
+            }
+            const double d = A[k][k];
+            const bool ok = fabs(d) > 0.0;
+            if (k == 0 && !ok) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) perm[j] = j;
+                bail = true;
+            } else if (ok) {
+#pragma unroll
+                for (int i = k + 1; i < 6; ++i) A[i][k] /= d;
             }
         }
-        const double d = A(k, k);
-        const bool ok = fabs(d) > 0.0;
-        if (k == 0 && !ok) {
-            for (int j = 0; j < 6; ++j) perm(j) = (double)j;
-            break;
-        }
-        if (ok)
-            for (int i = k + 1; i < 6; ++i) A(i, k) /= d;
     }
-    for (int i = 0; i < 6; ++i) x[i] = rhs[i];
-    for (int k = 0; k < 6; ++k) { const int pk = (int)perm(k); const double t = x[k]; x[k] = x[pk]; x[pk] = t; }
+    double x[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = sums27[21 + i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int p = k + 1; p < 6; ++p)
+            if (perm[k] == p) ICPMI_SWAP(x[k], x[p]);
+#pragma unroll
     for (int i = 1; i < 6; ++i) {
-        double s = 0.0;
-        for (int j = 0; j < i; ++j) s += A(i, j) * x[j];
-        x[i] -= s;
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < i; ++j) sacc += A[i][j] * x[j];
+        x[i] -= sacc;
     }
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
-        if (fabs(A(i, i)) > 2.2250738585072014e-308) x[i] /= A(i, i);
+        if (fabs(A[i][i]) > 2.2250738585072014e-308) x[i] /= A[i][i];
         else x[i] = 0.0;
     }
+#pragma unroll
     for (int i = 4; i >= 0; --i) {
-        double s = 0.0;
-        for (int j = i + 1; j < 6; ++j) s += A(j, i) * x[j];
-        x[i] -= s;
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) sacc += A[j][i] * x[j];
+        x[i] -= sacc;
     }
-    for (int k = 5; k >= 0; --k) { const int pk = (int)perm(k); const double t = x[k]; x[k] = x[pk]; x[pk] = t; }
-#undef A
-#undef perm
+#pragma unroll
+    for (int k = 5; k >= 0; --k)
+#pragma unroll
+        for (int p = k + 1; p < 6; ++p)
+            if (perm[k] == p) ICPMI_SWAP(x[k], x[p]);
+#undef ICPMI_SWAP
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xout[i] = x[i];
 }
 
 // x = [rx ry rz tx ty tz] -> row-major 4x4 (icp.hpp:123-143)

@@ -216,8 +216,7 @@ __device__ inline void finish_sums(const double *__restrict__ partials, int nblo
 }
 
 // error, convergence tests, solve, accumulate (icp.hpp:206-231 / 251-255)
-// `work`: 64 doubles of LDS for the 6x6 solve (run-time pivot indexing: not private memory)
-__device__ inline void step_update(IcpState *st, double *history, int final_pass, double *work)
+__device__ inline void step_update(IcpState *st, double *history, int final_pass)
 {
     if (st->done) {
         if (final_pass) {
@@ -250,16 +249,8 @@ __device__ inline void step_update(IcpState *st, double *history, int final_pass
         st->done = 1;
         return;
     }
-    double *M = work, *rhs = work + 36, *x = work + 42;
-    int o = 0;
-    for (int r = 0; r < 6; ++r)
-        for (int c = r; c < 6; ++c) {
-            M[r * 6 + c] = st->sums[o];
-            M[c * 6 + r] = st->sums[o];
-            ++o;
-        }
-    for (int r = 0; r < 6; ++r) rhs[r] = st->sums[21 + r];
-    ldlt6_solve(M, rhs, x, work + 48);   // icp.hpp:120
+    double x[6];
+    ldlt6_solve(st->sums, x);       // icp.hpp:120
     twist_to_transform(x, st->delta);    // icp.hpp:123-143
     mul44(st->delta, st->total, st->total); // icp.hpp:229
     st->prev_error = error;              // icp.hpp:231
@@ -274,18 +265,32 @@ __device__ __forceinline__ void publish_progress(int *progress, int ticket, cons
     if (progress) __hip_atomic_store(progress, ticket * 2 + (st->done ? 1 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The state is staged in LDS for the serial part: step_update touches ~100 of its words one
+// after the other, and each would otherwise be a round trip to device memory by a lone thread.
+static_assert(sizeof(IcpState) % 8 == 0, "IcpState is copied as 64-bit words");
+__device__ __forceinline__ void state_copy(void *dst, const void *src)
+{
+    const unsigned long long *s = static_cast<const unsigned long long *>(src);
+    unsigned long long *d = static_cast<unsigned long long *>(dst);
+    for (unsigned w = threadIdx.x; w < sizeof(IcpState) / 8; w += blockDim.x) d[w] = s[w];
+}
+
 __global__ __launch_bounds__(kFinishThreads) void k_finish_step(const double *__restrict__ partials,
                                                      int nblocks, int n_local, IcpState *st,
                                                      double *history, int final_pass, int *progress,
                                                      int ticket)
 {
-    __shared__ double work[64];
-    if (!st->done) finish_sums(partials, nblocks, n_local, st);
+    __shared__ IcpState ls;
+    state_copy(&ls, st);
+    __syncthreads();
+    if (!ls.done) finish_sums(partials, nblocks, n_local, &ls);
     __syncthreads();
     if (threadIdx.x == 0) {
-        step_update(st, history, final_pass, work);
-        publish_progress(progress, ticket, st);
+        step_update(&ls, history, final_pass);
+        publish_progress(progress, ticket, &ls);
     }
+    __syncthreads();
+    state_copy(st, &ls);
 }
 
 // multi GPU: k_finish -> ncclAllReduce(st->sums, 29) -> k_step
@@ -300,13 +305,17 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(const double *__restr
     finish_sums(partials, nblocks, n_local, st);
 }
 
-__global__ void k_step(IcpState *st, double *history, int final_pass, int *progress, int ticket)
+__global__ __launch_bounds__(64) void k_step(IcpState *st, double *history, int final_pass, int *progress, int ticket)
 {
-    __shared__ double work[64];
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        step_update(st, history, final_pass, work);
-        publish_progress(progress, ticket, st);
+    __shared__ IcpState ls;
+    state_copy(&ls, st);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        step_update(&ls, history, final_pass);
+        publish_progress(progress, ticket, &ls);
     }
+    __syncthreads();
+    state_copy(st, &ls);
 }
 
 // one-shot solve for icpmi_solve_point_to_plane (icp.hpp:89-144)
@@ -315,18 +324,9 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_solve(const double *_
 {
     finish_sums(partials, nblocks, n_local, st);
     __syncthreads();
-    __shared__ double work[64];
     if (threadIdx.x == 0) {
-        double *M = work, *rhs = work + 36, *x = work + 42;
-        int o = 0;
-        for (int r = 0; r < 6; ++r)
-            for (int c = r; c < 6; ++c) {
-                M[r * 6 + c] = st->sums[o];
-                M[c * 6 + r] = st->sums[o];
-                ++o;
-            }
-        for (int r = 0; r < 6; ++r) rhs[r] = st->sums[21 + r];
-        ldlt6_solve(M, rhs, x, work + 48);
+        double x[6];
+            ldlt6_solve(st->sums, x);
         twist_to_transform(x, st->delta);
     }
 }
