@@ -17,5 +17,6 @@ timeout -k 10 600 python scripts/bench_extra.py --c4 > "$O/bench_extra.json" 2> 
 timeout -k 10 200 python scripts/engine_compare.py > "$O/engines_100k.json" 2>&1 || exit 1
 timeout -k 10 300 python scripts/engine_compare.py 1000000 5 > "$O/engines_1m.json" 2>&1 || exit 1
 timeout -k 10 300 python scripts/shard_overhead.py > "$O/shard_overhead.json" 2>&1 || exit 1
+timeout -k 10 300 python scripts/engine_compare_lidar.py > "$O/engines_lidar_raw.json" 2>&1 || exit 1
 python scripts/prof_summary.py "$O" > "$O/summary.txt" 2>&1
 echo done
