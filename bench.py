@@ -246,6 +246,18 @@ def main():
                 out["parity"] = {"pose_dt_m": dt, "pose_dr_rad": dr,
                                  "num_iterations_equal": bool(r.num_iterations == res.num_iterations),
                                  "final_error_abs_diff": abs(r.final_error - res.final_error)}
+                # correspondence mismatches of one search pass (first-iteration geometry),
+                # GPU through the C ABI vs the oracle's kd-tree, and the normals of the target
+                from oracle import oracle as orc
+                nth = os.cpu_count() or 1
+                ctx.close()
+                ctx = capi.Context(device=local_rank, search=args.search)   # the engine `value` was measured with
+                gi, gd = ctx.nearest_batch(tgt, src)
+                oi, od = orc.KDTree(tgt).nearest_batch(src, nthreads=nth)
+                out["parity"]["nn_index_mismatches"] = int((gi != oi).sum())
+                out["parity"]["nn_sqdist_mismatches"] = int((gd != od).sum())
+                out["parity"]["normal_mismatches"] = int(
+                    (ctx.estimate_normals(tgt, 20) != orc.estimate_normals(tgt, None, 20, nthreads=nth)).any(axis=1).sum())
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_1thread"] = out["value"] / cb["value"]
         sys.stdout.flush()
