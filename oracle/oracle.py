@@ -229,3 +229,85 @@ def icp_point_to_plane(source, target, max_iterations=50, tolerance=1e-6, min_er
     r.final_seconds = res.final_seconds
     r.loop_iterations = res.loop_iterations
     return r
+
+
+# ---------------------------------------------------------------------------------------------
+# Optional direct-oracle hook (oracle/ref_hook.cpp): the REFERENCE's own code behind a C wrapper,
+# available only where Eigen3 and a reference checkout exist (not in the build image: `make ref`
+# says so and builds nothing).  Used by tests/test_reference_hook.py to pin this oracle against
+# the reference when it can be built; never by the product.
+# ---------------------------------------------------------------------------------------------
+_REF = None
+
+
+def build_ref():
+    """Path of oracle/_ref/libslam_ref.so, building it if possible; None when the reference
+    cannot be built here (no Eigen3 / no checkout)."""
+    so = os.path.join(_HERE, "_ref", "libslam_ref.so")
+    if not os.path.exists(so):
+        subprocess.call(["make", "-s", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return so if os.path.exists(so) else None
+
+
+def ref_lib():
+    global _REF
+    if _REF is None:
+        so = build_ref()
+        if so is None:
+            return None
+        L = C.CDLL(so)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        L.ref_icp_point_to_plane.restype = C.c_int
+        L.ref_icp_point_to_plane.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_double, C.c_double, dp,
+                                             dp, ip, ip, dp, dp, C.c_int]
+        L.ref_nearest_batch.argtypes = [dp, C.c_int, dp, C.c_int, ip, dp]
+        L.ref_estimate_normals.argtypes = [dp, C.c_int, C.c_int, dp]
+        L.ref_solve_point_to_plane.argtypes = [dp, dp, dp, C.c_int, dp]
+        _REF = L
+    return _REF
+
+
+def ref_icp_point_to_plane(source, target, max_iterations=50, tolerance=1e-6, min_error=1e-9,
+                           initial_transform=None):
+    """slam::icp_point_to_plane itself -> (T 4x4, converged, num_iterations, final_error, history)."""
+    L = ref_lib()
+    s, sp = _d(source)
+    t, tp = _d(target)
+    T0 = np.ascontiguousarray(np.eye(4) if initial_transform is None else initial_transform, dtype=np.float64)
+    T = np.zeros(16)
+    conv, iters, ferr = C.c_int(0), C.c_int(0), C.c_double(0.0)
+    hist = np.zeros(max_iterations + 2)
+    n = L.ref_icp_point_to_plane(sp, s.shape[0], tp, t.shape[0], max_iterations, tolerance, min_error,
+                                 T0.ctypes.data_as(C.POINTER(C.c_double)), T.ctypes.data_as(C.POINTER(C.c_double)),
+                                 C.byref(conv), C.byref(iters), C.byref(ferr),
+                                 hist.ctypes.data_as(C.POINTER(C.c_double)), hist.shape[0])
+    return T.reshape(4, 4), bool(conv.value), iters.value, ferr.value, hist[:n].copy()
+
+
+def ref_nearest_batch(targets, queries):
+    L = ref_lib()
+    t, tp = _d(targets)
+    q, qp = _d(queries)
+    idx = np.empty(q.shape[0], dtype=np.int32)
+    d2 = np.empty(q.shape[0], dtype=np.float64)
+    L.ref_nearest_batch(tp, t.shape[0], qp, q.shape[0], idx.ctypes.data_as(C.POINTER(C.c_int)),
+                        d2.ctypes.data_as(C.POINTER(C.c_double)))
+    return idx, d2
+
+
+def ref_estimate_normals(points, k=20):
+    L = ref_lib()
+    p, pp = _d(points)
+    out = np.empty_like(p)
+    L.ref_estimate_normals(pp, p.shape[0], k, out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def ref_solve_point_to_plane(source, target, normals):
+    L = ref_lib()
+    s, sp = _d(source)
+    t, tp = _d(target)
+    n, np_ = _d(normals)
+    T = np.zeros(16)
+    L.ref_solve_point_to_plane(sp, tp, np_, s.shape[0], T.ctypes.data_as(C.POINTER(C.c_double)))
+    return T.reshape(4, 4)
