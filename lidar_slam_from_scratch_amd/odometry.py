@@ -85,6 +85,49 @@ def gpu_align(ctx):
     return align
 
 
+def run_odometry_device(raw_frames, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6, min_points=1000):
+    """The same loop with the clouds resident in HBM: each RAW scan is
+    uploaded once, voxel-filtered on the device (slam_node.cpp:122 -> icpmi_voxel_downsample_device)
+    and registered against the previous filtered scan, which never left the device
+    (slam_node.cpp:132-133,152: the target of frame t+1 is the source of frame t).
+    torch is used for device memory only."""
+    import torch
+    from . import capi
+    track = OdometryTrack()
+    prev = None       # (tensor, rows)
+    cfg = capi.Context.make_config(max_iterations=max_iterations, tolerance=tolerance)
+    for k, raw in enumerate(raw_frames):
+        t0 = time.perf_counter()
+        d_raw = torch.from_numpy(np.ascontiguousarray(raw, dtype=np.float64)).cuda()
+        d_cur = torch.empty_like(d_raw)
+        n = ctx.voxel_downsample_device(d_raw.data_ptr(), d_raw.shape[0], voxel, d_cur.data_ptr(), d_raw.shape[0])
+        if k == 0:
+            prev = (d_cur, n)              # slam_node.cpp:69-72
+            continue
+        if n < min_points:                 # slam_node.cpp:125-130
+            track.poses.append(track.poses[-1].copy())
+            track.deltas.append(np.eye(4))
+            track.final_errors.append(float("nan"))
+            track.iterations.append(0)
+            track.converged.append(False)
+            track.gated.append(True)
+            prev = (d_cur, n)
+            track.frame_ms.append(1e3 * (time.perf_counter() - t0))
+            continue
+        res, _hist = ctx.align_device(d_cur.data_ptr(), n, prev[0].data_ptr(), prev[1], cfg)
+        bad = (not res.converged) or res.final_error > 1.0   # slam_node.cpp:139-140
+        delta = np.eye(4) if bad else np.array(res.transformation[:]).reshape(4, 4)
+        track.poses.append(track.poses[-1] @ delta)           # slam_node.cpp:142
+        track.deltas.append(delta)
+        track.final_errors.append(res.final_error)
+        track.iterations.append(res.num_iterations)
+        track.converged.append(bool(res.converged))
+        track.gated.append(bool(bad))
+        prev = (d_cur, n)                                     # slam_node.cpp:152
+        track.frame_ms.append(1e3 * (time.perf_counter() - t0))
+    return track
+
+
 def absolute_trajectory_error(track, truth_poses):
     """RMS translation error against ground-truth poses expressed relative to frame 0."""
     t0_inv = np.linalg.inv(truth_poses[0])

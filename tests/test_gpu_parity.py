@@ -400,6 +400,28 @@ def test_odometry_stream_matches_oracle(gpu_ctx, oracle):
                - odometry.absolute_trajectory_error(ref, truth)) < 1e-9
 
 
+def test_device_resident_odometry_matches_oracle(gpu_ctx, oracle):
+    """The stream with the clouds kept in HBM: raw scan -> voxel filter on the device ->
+    registration against the previous filtered scan (device pointers throughout).  The oracle
+    loop filters with orc_voxel_downsample (same key order, bit-identical centroids) and runs
+    the CPU ICP: same iteration counts, gates and poses."""
+    from lidar_slam_from_scratch_amd import odometry
+
+    raw = [synth.lidar_frame(f, voxel=0, beams=32, azimuths=900) for f in range(4)]
+    raw.insert(2, raw[1][::40][:700])          # a scan too small after filtering: min_points guard
+
+    def oracle_align(src, tgt, max_it, tol):
+        return oracle.icp_point_to_plane(src, tgt, max_it, tol, 1e-9)
+
+    ref = odometry.run_odometry([oracle.voxel_downsample(r, 0.5) for r in raw], oracle_align)
+    got = odometry.run_odometry_device(raw, gpu_ctx, voxel=0.5)
+    assert got.iterations == ref.iterations and got.gated == ref.gated and got.converged == ref.converged
+    assert got.gated[1] and got.iterations[1] == 0
+    for a, b in zip(got.poses, ref.poses):
+        dt, dr = synth.pose_delta(a, b)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_error_codes(gpu_ctx):
     cfg = capi.Context.make_config()
