@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 CSV output (kernel stats or pmc counter rows) into a short table."""
+import signal
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)  # `| head` closes the pipe early: end quietly
 import csv, glob, sys, collections
 d = sys.argv[1]
 for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
