@@ -596,3 +596,60 @@ def test_pruned_engine_skips_blocks_and_keeps_the_result(case, oracle):
     assert dt < 1e-10 and dr < 1e-10
     ref = oracle.icp_point_to_plane(src, tgt, **kw)
     check_against(b, hb, ref.transformation, ref.converged, ref.num_iterations, ref.error_history)
+
+
+def _fuzz_cloud(rng, kind, n):
+    """Clouds whose bounding boxes make culling hard: sheets, lines, clusters, far outliers."""
+    if kind == "sheet":        # a thin, tilted plane: flat boxes overlapping many splits
+        p = np.c_[rng.uniform(-40, 40, n), rng.uniform(-40, 40, n), rng.normal(0, 0.02, n)]
+        R = synth.make_transform((0.3, 0.2, 0.1), (0, 0, 0))[:3, :3]
+        return p @ R.T
+    if kind == "lines":        # a few long segments: 1-D structure
+        a = rng.uniform(-30, 30, (6, 3))
+        b = rng.uniform(-30, 30, (6, 3))
+        k = rng.integers(0, 6, n)
+        t = rng.uniform(0, 1, (n, 1))
+        return a[k] * (1 - t) + b[k] * t + rng.normal(0, 0.05, (n, 3))
+    if kind == "clusters":     # dense blobs + sparse background
+        c = rng.uniform(-50, 50, (25, 3))
+        p = c[rng.integers(0, 25, n)] + rng.normal(0, 0.8, (n, 3))
+        p[: n // 20] = rng.uniform(-60, 60, (n // 20, 3))
+        return p
+    if kind == "outliers":     # a compact cloud and a handful of points very far away
+        p = rng.uniform(-10, 10, (n, 3))
+        p[:8] = rng.uniform(-1, 1, (8, 3)) * 5.0e3
+        return p
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind,seed", [("sheet", 1), ("lines", 2), ("clusters", 3), ("outliers", 4),
+                                       ("sheet", 5), ("clusters", 6)])
+def test_engines_agree_on_awkward_geometry(kind, seed):
+    """All-pairs vs pruned engine (and the fp64 engine on the first search) on clouds built to
+    stress the bounding-box cull: identical correspondences -> identical history; sizes that are
+    not multiples of the block (512) or the split (2048); a large initial misalignment."""
+    rng = np.random.default_rng(seed)
+    m = int(rng.integers(8200, 20000))
+    n = int(rng.integers(3000, 15000))
+    tgt = _fuzz_cloud(rng, kind, m)
+    T = synth.make_transform(rng.normal(0, 0.03, 3), rng.normal(0, 0.4, 3))
+    pick = rng.integers(0, m, n)
+    src = (tgt[pick] + rng.normal(0, 0.01, (n, 3)) - T[:3, 3]) @ T[:3, :3]
+    T0 = synth.make_transform(rng.normal(0, 0.2, 3), rng.normal(0, 3.0, 3)) if seed % 2 else np.eye(4)
+    cfg = capi.Context.make_config(12, 0.0, 0.0, initial_transform=T0)
+    out = {}
+    for name, eng in (("all", capi.SEARCH_MFMA_BF16), ("pruned", capi.SEARCH_MFMA_PRUNED), ("f64", capi.SEARCH_EXACT_F64)):
+        ctx = capi.Context(device=0, search=eng, profile=1)
+        try:
+            res, hist = ctx.align(src, tgt, cfg)
+            moved = (src @ T0[:3, :3].T) + T0[:3, 3]
+            out[name] = (T_of(res), hist, ctx.nearest_batch(tgt, moved)[0], ctx.estimate_normals(tgt, 20))
+        finally:
+            ctx.close()
+    for other in ("pruned", "f64"):
+        assert (out[other][2] == out["all"][2]).all()                       # first correspondences, bit for bit
+        assert (out[other][3] == out["all"][3]).all()                       # normals, bit for bit
+        assert len(out[other][1]) == len(out["all"][1])
+        np.testing.assert_allclose(out[other][1], out["all"][1], rtol=1e-9, atol=1e-12)
+        dt, dr = synth.pose_delta(out[other][0], out["all"][0])
+        assert dt < 1e-8 and dr < 1e-8
