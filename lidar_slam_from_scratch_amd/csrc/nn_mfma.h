@@ -42,6 +42,13 @@
 //     (2u x the largest magnitude, <= a^2): 34 u a^2; plus fl32(|Q|^2), fl32(|P|^2) formed
 //     with 5 roundings, and the final add: 41 u a^2.  48 u a^2 is used.
 //   column tag: < 2^-19 relative on the stored minimum (inflation 4e-6 covers it).
+//
+// Engine 3 (ICPMI_SEARCH_MFMA_PRUNED, opt-in) runs the same coarse unit and the same resolve on
+// fewer (query block, split) units: k_transform_bounds / k_knn_block_bounds bound, per block of
+// 512 queries, the distance within which every query finds its answer, cull_block keeps the
+// splits whose bounding box is within that distance of the block's, k_nn_coarse_list walks the
+// surviving units and the resolves read each block's split list.  The cull is conservative
+// (strict inequality, margins for its own roundings), so the result is the same, ties included.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
