@@ -952,6 +952,7 @@ int icpmi_nearest_batch(icpmi_ctx *ctx, const double *targets_xyz, int64_t n_tgt
     if (!targets_xyz || !queries_xyz || !indices) return fail(ctx, ICPMI_ERR_NULL, "null argument");
     if (n_tgt <= 0) return fail(ctx, ICPMI_ERR_EMPTY_TARGET, "empty target cloud");
     if (n_qry < 0) return fail(ctx, ICPMI_ERR_ARG, "n_qry < 0");
+    if (n_qry > (int64_t)700000000 || n_tgt > (int64_t)700000000) return fail(ctx, ICPMI_ERR_ARG, "cloud larger than 7e8 points");
     if (n_qry == 0) return ICPMI_OK;
     const int n = (int)n_qry, m = (int)n_tgt;
     if ((rc = reserve(ctx, ctx->stage_b, sizeof(double) * 3 * (size_t)n))) return rc;
@@ -980,6 +981,7 @@ int icpmi_estimate_normals(icpmi_ctx *ctx, const double *points_xyz, int64_t n, 
     if ((rc = check_common(ctx))) return rc;
     if (!points_xyz || !normals_xyz) return fail(ctx, ICPMI_ERR_NULL, "null argument");
     if (n <= 0) return fail(ctx, ICPMI_ERR_EMPTY_TARGET, "empty cloud");
+    if (n > (int64_t)700000000) return fail(ctx, ICPMI_ERR_ARG, "cloud larger than 7e8 points");
     if (k < 1 || k > 64) return fail(ctx, ICPMI_ERR_ARG, "k %d outside [1,64]", k);
     const int m = (int)n;
     if ((rc = reserve(ctx, ctx->stage_c, sizeof(double) * 3 * (size_t)m))) return rc;
@@ -1003,6 +1005,7 @@ int icpmi_solve_point_to_plane(icpmi_ctx *ctx, const double *source_xyz, const d
     if (!source_xyz || !target_xyz || !normals_xyz || !transform_out)
         return fail(ctx, ICPMI_ERR_NULL, "null argument");
     if (n64 <= 0) return fail(ctx, ICPMI_ERR_EMPTY_SOURCE, "empty correspondence set");
+    if (n64 > (int64_t)700000000) return fail(ctx, ICPMI_ERR_ARG, "more than 7e8 correspondences");
     const int n = (int)n64;
     const size_t bytes = sizeof(double) * 3 * (size_t)n;
     if ((rc = reserve(ctx, ctx->stage_a, bytes))) return rc;
@@ -1037,7 +1040,7 @@ int icpmi_transform_points(icpmi_ctx *ctx, const double transform[16], const dou
     int rc;
     if ((rc = check_common(ctx))) return rc;
     if (!transform || !in_xyz || !out_xyz) return fail(ctx, ICPMI_ERR_NULL, "null argument");
-    if (n64 < 0) return fail(ctx, ICPMI_ERR_ARG, "n < 0");
+    if (n64 < 0 || n64 > (int64_t)700000000) return fail(ctx, ICPMI_ERR_ARG, "n out of range");
     if (n64 == 0) return ICPMI_OK;
     const int n = (int)n64;
     const size_t bytes = sizeof(double) * 3 * (size_t)n;
