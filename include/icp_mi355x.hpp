@@ -8,6 +8,10 @@
 //   slam::ICPConfig             types.hpp:143-148        ICPConfig
 //   slam::ICPResult             types.hpp:155-164        ICPResult
 //   slam::icp_point_to_plane    icp.hpp:157-161          icp_point_to_plane
+//   slam::KDTree                kdtree.hpp:18-186        KDTree (nearest, nearest_batch)
+//   slam::NearestNeighborSearch kdtree.hpp:193-221       NearestNeighborSearch (find_correspondences)
+//   slam::estimate_normals      icp.hpp:23-67            estimate_normals
+//   slam::solve_point_to_plane  icp.hpp:89-144           solve_point_to_plane
 //   (north_star wording)                                 ICP::align
 //
 // A caller that already has Eigen and the reference's own types uses
@@ -15,6 +19,7 @@
 #pragma once
 
 #include <array>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <stdexcept>
@@ -231,6 +236,92 @@ inline PointCloud voxel_downsample(Context &ctx, const PointCloud &points, doubl
 inline PointCloud voxel_downsample(const PointCloud &points, double voxel_size)
 {
     return voxel_downsample(default_context(), points, voxel_size);
+}
+
+// ---- stage-level mirrors (the pieces slam::icp_point_to_plane is made of) ------------------------
+// slam::KDTree (kdtree.hpp:18-186).  The device search needs no tree: the object keeps the target
+// rows (as the reference's constructor copies them, kdtree.hpp:20) and searches through the C ABI.
+class KDTree {
+public:
+    explicit KDTree(const PointCloud &points, Context *ctx = nullptr) : pts_(points.copy()), ctx_(ctx) {}
+    std::size_t size() const { return pts_.size(); }
+    const PointCloud &points() const { return pts_; }
+    // kdtree.hpp:43-59: nearest target row and squared distance for every query row
+    void nearest_batch(const PointCloud &queries, std::vector<int> &indices, std::vector<double> &distances_sq) const
+    {
+        indices.assign(queries.size(), -1);
+        distances_sq.assign(queries.size(), 0.0);
+        if (queries.empty()) return;
+        Context &c = ctx_ ? *ctx_ : default_context();
+        std::vector<int32_t> idx(queries.size());
+        int rc = icpmi_nearest_batch(c.get(), pts_.data(), static_cast<int64_t>(pts_.size()), queries.data(),
+                                     static_cast<int64_t>(queries.size()), idx.data(), distances_sq.data());
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(c.get()));
+        for (std::size_t i = 0; i < idx.size(); ++i) indices[i] = idx[i];
+    }
+    // kdtree.hpp:28-38: (index, squared distance) of the nearest row to one point
+    std::pair<int, double> nearest(const std::array<double, 3> &query) const
+    {
+        std::vector<int> i;
+        std::vector<double> d;
+        nearest_batch(PointCloud(query.data(), 1), i, d);
+        return {i[0], d[0]};
+    }
+
+private:
+    PointCloud pts_;
+    Context *ctx_;
+};
+
+// slam::NearestNeighborSearch (kdtree.hpp:193-221)
+class NearestNeighborSearch {
+public:
+    explicit NearestNeighborSearch(const PointCloud &target, Context *ctx = nullptr) : tree_(target, ctx) {}
+    const KDTree &tree() const { return tree_; }
+    // kdtree.hpp:198-214: matched_target.row(i) = target.row(nearest(i)), distances = sqrt(d^2)
+    void find_correspondences(const PointCloud &source, PointCloud &matched_target, std::vector<double> &distances) const
+    {
+        std::vector<int> idx;
+        std::vector<double> d2;
+        tree_.nearest_batch(source, idx, d2);
+        std::vector<double> rows(3 * source.size());
+        distances.resize(source.size());
+        for (std::size_t i = 0; i < source.size(); ++i) {
+            const double *q = tree_.points().row(static_cast<std::size_t>(idx[i]));
+            rows[3 * i] = q[0];
+            rows[3 * i + 1] = q[1];
+            rows[3 * i + 2] = q[2];
+            distances[i] = std::sqrt(d2[i]);
+        }
+        matched_target = PointCloud(std::move(rows));
+    }
+
+private:
+    KDTree tree_;
+};
+
+// slam::estimate_normals (icp.hpp:23-67): unit normals of `points` from their k nearest neighbours
+inline PointCloud estimate_normals(const PointCloud &points, int k = 20, Context *ctx = nullptr)
+{
+    Context &c = ctx ? *ctx : default_context();
+    std::vector<double> out(3 * points.size());
+    int rc = icpmi_estimate_normals(c.get(), points.data(), static_cast<int64_t>(points.size()), k, out.data());
+    if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(c.get()));
+    return PointCloud(std::move(out));
+}
+
+// slam::solve_point_to_plane (icp.hpp:89-144): one linearised step for given correspondences
+inline Transformation solve_point_to_plane(const PointCloud &source, const PointCloud &target, const PointCloud &normals,
+                                           Context *ctx = nullptr)
+{
+    if (source.size() != target.size() || source.size() != normals.size())
+        throw std::invalid_argument("solve_point_to_plane: row counts differ");
+    Context &c = ctx ? *ctx : default_context();
+    std::array<double, 16> T{};
+    int rc = icpmi_solve_point_to_plane(c.get(), source.data(), target.data(), normals.data(),
+                                        static_cast<int64_t>(source.size()), T.data());
+    if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(c.get()));
+    return Transformation(T);
 }
 
 // `ICP(config).align(source, target)`: the facade BASELINE.json's north_star names.

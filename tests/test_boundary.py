@@ -117,7 +117,13 @@ def test_cpp_adapter_compiles_against_a_minimal_cloud_type(tmp_path):
         '#include "icp_mi355x.hpp"\n'
         "int main(){ icp_mi355x::PointCloud a, b; icp_mi355x::ICPConfig c;\n"
         " try { auto r = icp_mi355x::icp_point_to_plane(a, b, c); return r.converged ? 1 : 0; }\n"
-        " catch (const std::exception&) { return 0; } }\n")
+        " catch (const std::exception&) { }\n"
+        " // the stage-level mirrors must at least instantiate (no device here: every call throws)\n"
+        " try { icp_mi355x::NearestNeighborSearch nn(b); icp_mi355x::PointCloud mt; std::vector<double> d;\n"
+        "       nn.find_correspondences(a, mt, d); nn.tree().nearest({0.0, 0.0, 0.0}); } catch (const std::exception&) { }\n"
+        " try { icp_mi355x::estimate_normals(b, 20); } catch (const std::exception&) { }\n"
+        " try { icp_mi355x::solve_point_to_plane(a, b, b); } catch (const std::exception&) { }\n"
+        " return 0; }\n")
     exe = tmp_path / "t"
     subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src),
                            "-o", str(exe), build.LIB_PATH, "-Wl,-rpath," + os.path.dirname(build.LIB_PATH),

@@ -653,3 +653,41 @@ def test_engines_agree_on_awkward_geometry(kind, seed):
         np.testing.assert_allclose(out[other][1], out["all"][1], rtol=1e-9, atol=1e-12)
         dt, dr = synth.pose_delta(out[other][0], out["all"][0])
         assert dt < 1e-8 and dr < 1e-8
+
+
+def test_cpp_mirror_end_to_end(tmp_path, oracle):
+    """include/icp_mi355x.hpp on the GPU from a plain C++17 program (tests/cpp/mirror_demo.cpp):
+    NearestNeighborSearch, estimate_normals, solve_point_to_plane and ICP::align against the oracle."""
+    import subprocess
+    from lidar_slam_from_scratch_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "mirror_demo"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "mirror_demo.cpp"), "-o", str(exe), build.LIB_PATH,
+                           "-Wl,-rpath," + os.path.dirname(build.LIB_PATH), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
+                           "-lamdhip64"])
+    src, tgt, _ = synth.c1_room_corner(3000)
+    src.tofile(tmp_path / "s.f64")
+    tgt.tofile(tmp_path / "t.f64")
+    subprocess.check_call([str(exe), str(tmp_path / "s.f64"), str(tmp_path / "t.f64"), str(tmp_path / "o.f64")])
+    o = np.fromfile(tmp_path / "o.f64")
+    n, m = int(o[0]), int(o[1])
+    assert (n, m) == (src.shape[0], tgt.shape[0])
+    p = 2
+    idx = o[p:p + n].astype(np.int64); p += n
+    dist = o[p:p + n]; p += n
+    nrm = o[p:p + 3 * m].reshape(m, 3); p += 3 * m
+    Ts = o[p:p + 16].reshape(4, 4); p += 16
+    Ti = o[p:p + 16].reshape(4, 4); p += 16
+    conv, iters, ferr, hl = bool(o[p]), int(o[p + 1]), o[p + 2], int(o[p + 3]); p += 4
+    hist = o[p:p + hl]
+    oidx, od2 = oracle.KDTree(tgt).nearest_batch(src)
+    assert (idx == oidx).all() and (dist == np.sqrt(od2)).all()
+    onrm = oracle.estimate_normals(tgt, None, 20)
+    assert (nrm == onrm).all()
+    np.testing.assert_allclose(Ts, oracle.solve_point_to_plane(src, tgt[oidx], onrm[oidx]), atol=1e-12)
+    ref = oracle.icp_point_to_plane(src, tgt)
+    assert conv == ref.converged and iters == ref.num_iterations and ferr == hist[-1]
+    dt, dr = synth.pose_delta(Ti, ref.transformation)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+    np.testing.assert_allclose(hist, ref.error_history, atol=HIST_TOL)
