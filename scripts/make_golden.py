@@ -72,8 +72,22 @@ def fixture(name, src, tgt, max_it=50, tol=1e-6, min_err=1e-9, store_inputs=Fals
     print(name, "iters", r.num_iterations, "conv", r.converged, "err", r.final_error)
 
 
+def widening_fixture():
+    """Rows N1/N2 of SURVEY 8(f): voxel filter (file_utils.cpp:148-196) and Scan Context
+    (scan_context.hpp:44-142) of a raw synthetic scan, from the oracle."""
+    raw = synth.lidar_frame(0, voxel=0, beams=32, azimuths=900)
+    vox = orc.voxel_downsample(raw, 0.5)
+    other = orc.voxel_downsample(synth.lidar_frame(3, voxel=0, beams=32, azimuths=900), 0.5)
+    d = dict(raw_crc=crc(raw), voxel_size=0.5, voxel_rows=vox.shape[0], voxel_crc=crc(vox), voxel_head=vox[:16],
+             sc_desc=orc.scan_context(vox), sc_desc_other=orc.scan_context(other),
+             sc_distance=orc.scan_context_distance(orc.scan_context(vox), orc.scan_context(other)))
+    np.savez_compressed(os.path.join(OUT, "widening.npz"), **d)
+    print("widening: voxels", vox.shape[0], "sc distance", d["sc_distance"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    widening_fixture()
     s, t, _ = synth.c1_room_corner()
     fixture("c1_room_corner", s, t)
     s, t, _ = synth.kat1_exact_pair()

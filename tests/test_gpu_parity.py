@@ -691,3 +691,16 @@ def test_cpp_mirror_end_to_end(tmp_path, oracle):
     dt, dr = synth.pose_delta(Ti, ref.transformation)
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
     np.testing.assert_allclose(hist, ref.error_history, atol=HIST_TOL)
+
+
+def test_widening_matches_golden(gpu_ctx):
+    """Voxel filter and Scan Context on the GPU against tests/golden/widening.npz."""
+    g = np.load(os.path.join(GOLD, "widening.npz"))
+    raw = synth.lidar_frame(0, voxel=0, beams=32, azimuths=900)
+    assert crc(raw) == g["raw_crc"], "generator drifted"
+    vox = gpu_ctx.voxel_downsample(raw, float(g["voxel_size"]))
+    assert vox.shape[0] == int(g["voxel_rows"]) and crc(vox) == g["voxel_crc"]
+    desc = gpu_ctx.scan_context(vox)
+    assert (desc != g["sc_desc"].reshape(desc.shape)).sum() <= 2      # atan2 last-ulp at sector edges (DESIGN 7, N2)
+    d = gpu_ctx.scan_context_distances(g["sc_desc"], g["sc_desc_other"][None])
+    assert d[0] == float(g["sc_distance"])
