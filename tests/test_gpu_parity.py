@@ -704,3 +704,29 @@ def test_widening_matches_golden(gpu_ctx):
     assert (desc != g["sc_desc"].reshape(desc.shape)).sum() <= 2      # atan2 last-ulp at sector edges
     d = gpu_ctx.scan_context_distances(g["sc_desc"], g["sc_desc_other"][None])
     assert d[0] == float(g["sc_distance"])
+
+
+def test_context_churn_does_not_leak_device_memory():
+    """Every icpmi_create is matched by an icpmi_destroy that returns all device memory
+    (workspaces, events, stream, RCCL-free path): free memory after 40 create/align/destroy
+    rounds, all engines, is what it was after the first."""
+    import torch
+    src, tgt, _ = synth.c3_uniform(12000, seed=8, perm_seed=9)
+    cfg = capi.Context.make_config(3, 0.0, 0.0)
+
+    def one(engine):
+        ctx = capi.Context(device=0, search=engine, profile=2)
+        ctx.align(src, tgt, cfg)
+        ctx.voxel_downsample(tgt, 1.0)
+        ctx.estimate_normals(tgt, 20)
+        ctx.close()
+
+    for e in (1, 2, 3):
+        one(e)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for r in range(40):
+        one(1 + r % 3)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)
