@@ -61,6 +61,20 @@ def cpu_baseline(src, tgt, steps):
     }
 
 
+def self_launch(n):
+    """Run this script under torch.distributed.run with n ranks on 127.0.0.1; returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,7 +91,16 @@ def main():
                     help="rehearsal on one GPU: take the multi-rank code path (process group, RCCL communicator "
                          "inside the library, sharded kernels) with a world of 1")
     ap.add_argument("--cpu-steps", type=int, default=None)
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="rehearsal of the N-rank run where RCCL cannot form a communicator (several ranks sharing "
+                         "one GPU): process group over gloo, the library's two exchanges through host callbacks")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process
+        # per GPU.  This parent makes no GPU call (it does not even import torch): it only waits
+        # for the ranks; rank 0 prints the one JSON line on the stdout it inherits.
+        sys.exit(self_launch(args.gpus))
 
     # stdout carries exactly one line, the JSON: whatever a library prints there (RCCL announces
     # its version on stdout when a communicator is created) is sent to stderr instead
@@ -92,8 +115,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d "
+                         "(or with no launcher at all: bench.py starts its own ranks)" % (args.gpus, world, args.gpus))
+    if args.rehearse_gloo:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -103,7 +128,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     src, tgt, _T = synth.c3_uniform(args.points)
     lo, hi = icpdist.shard_bounds(src.shape[0], world, rank)
@@ -115,7 +143,10 @@ def main():
     # (the fp64 engine has no single dominant kernel bracket: time its whole NN pass instead)
     ctx = capi.Context(device=local_rank, search=args.search, profile=2 if args.search == 1 else 1)
     if dist is not None:
-        icpdist.init_rccl(ctx, dist, device=dev, allow_single=args.force_dist)
+        if args.rehearse_gloo:
+            icpdist.init_callbacks(ctx, dist)
+        else:
+            icpdist.init_rccl(ctx, dist, device=dev, allow_single=args.force_dist)
 
     def call(iters):
         cfg = capi.Context.make_config(max_iterations=iters, tolerance=0.0, min_error=0.0)
@@ -136,7 +167,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = ctx.get_profile()
@@ -212,7 +243,9 @@ def main():
             "config": {"workload": "C3: synthetic %d->%d-pt uniform random scan, %d ICP iterations, "
                                    "1 call incl. 20-NN normals + final pass" % (src.shape[0], m, args.steps),
                        "source_points": int(src.shape[0]), "target_points": int(m),
-                       "parallelism": "source sharded x%d, 29-double RCCL all-reduce/iter" % world
+                       "parallelism": ("source sharded x%d, REHEARSAL (not a scaling number): ranks share GPUs, "
+                                       "exchange through gloo host callbacks" % world) if args.rehearse_gloo
+                       else "source sharded x%d, 29-double RCCL all-reduce/iter" % world
                        if dist is not None else "single GPU",
                        "search": "bf16 MFMA coarse pass over all pairs + certified fp64 resolve" if mfma
                        else "exact fp64 brute force"},

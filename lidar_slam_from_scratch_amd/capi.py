@@ -70,6 +70,46 @@ class IcpError(RuntimeError):
 _LIB = None
 
 
+def hip_runtimes_mapped(maps_text=None):
+    """Distinct libamdhip64 images mapped into this process (real paths), from /proc/self/maps."""
+    if maps_text is None:
+        try:
+            with open("/proc/self/maps") as f:
+                maps_text = f.read()
+        except OSError:
+            return []
+    seen = []
+    for line in maps_text.splitlines():
+        parts = line.split(None, 5)
+        if len(parts) == 6 and os.path.basename(parts[5]).startswith("libamdhip64"):
+            path = parts[5].strip()
+            if path not in seen:
+                seen.append(path)
+    return seen
+
+
+def _one_hip_runtime(before_dlopen):
+    """One HIP runtime per process.  libicp_mi355x.so needs `libamdhip64.so.7`; the torch wheel
+    bundles its own copy (SONAME libamdhip64.so.7, but torch's libraries ask for it as
+    `libamdhip64.so`, which the dynamic loader does not recognise as the image /opt/rocm already
+    provided).  Library first, torch second therefore maps TWO runtimes, and the first stream or
+    event handed from one to the other aborts the process (`std::bad_variant_access`).  Torch
+    first, library second resolves both to torch's copy.  So: import torch before the dlopen if
+    it is there to be imported, and refuse to go on if two runtimes are mapped anyway."""
+    import sys
+    if before_dlopen:
+        if "torch" not in sys.modules:
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
+        return
+    mapped = hip_runtimes_mapped()
+    if len(mapped) > 1:
+        raise IcpError(ERR_HIP, "two HIP runtimes are mapped into this process (%s): libicp_mi355x.so must "
+                                "share torch's; import torch before anything loads /opt/rocm's libamdhip64"
+                       % ", ".join(mapped))
+
+
 def load_library(path=None):
     """dlopen the in-tree libicp_mi355x.so (must have been built: see build.build_library)."""
     global _LIB
@@ -80,7 +120,9 @@ def load_library(path=None):
         raise FileNotFoundError(
             "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback)" % path)
+    _one_hip_runtime(before_dlopen=True)
     L = C.CDLL(path)
+    _one_hip_runtime(before_dlopen=False)
     dp, vp = C.POINTER(C.c_double), C.c_void_p
     L.icpmi_version.restype = C.c_char_p
     L.icpmi_options_default.argtypes = [C.POINTER(Options)]
