@@ -18,6 +18,11 @@
  *     of the last failure is available from icpmi_last_error().
  *   - one icpmi_ctx serves one caller thread at a time; distinct contexts may run
  *     concurrently.  Calls block until results are on the host.
+ *   - stream ordering of the *_device entry points: the library works on a private
+ *     non-blocking HIP stream that is NOT ordered against any stream of the caller
+ *     (torch's current stream included).  Device inputs must be complete and visible
+ *     before the call (synchronise the producing stream, or wait on its event, first);
+ *     device outputs are complete when the call returns.
  *   - there is no CPU fallback: with no usable HIP device icpmi_create fails.
  */
 #ifndef ICP_MI355X_H
@@ -171,8 +176,15 @@ int icpmi_scan_context_distances(icpmi_ctx *ctx, const double *query_desc, const
 /* Multi-GPU (new; the reference has no distributed path).  One process per GPU.  Rank 0
  * obtains an id, the host distributes it (e.g. torch.distributed broadcast), every rank
  * calls icpmi_comm_init.  Afterwards icpmi_align* treats `source` as this rank's shard
- * of the source cloud; the target is replicated.  Each iteration all-reduces 29 doubles
- * (21 J^T J + 6 J^T b + sum b^2 + count) over RCCL. */
+ * of the source cloud; the target is replicated.  Each iteration all-reduces 30 doubles
+ * (21 J^T J + 6 J^T b + sum b^2 + count + the number of ranks whose loop has ended) over RCCL.
+ * Every rank must make the same calls with the same icpmi_config and target.  A shard may be
+ * empty (n_src == 0, source pointer ignored) as long as some rank holds points: it adds
+ * nothing to the sums and takes part in every exchange.  The ranks stop on the exchanged
+ * count of finished loops, never on a local decision, so they always queue the same number
+ * of collectives; if they did not all finish at the same iteration (configs differ, or an
+ * exchange that is not bit-identical on every rank) every rank returns ICPMI_ERR_RCCL from
+ * that call instead of waiting for the others forever. */
 #define ICPMI_UNIQUE_ID_BYTES 128
 int icpmi_comm_unique_id(icpmi_ctx *ctx, void *id_out /* ICPMI_UNIQUE_ID_BYTES */);
 int icpmi_comm_init(icpmi_ctx *ctx, int32_t n_ranks, int32_t rank, const void *id);

@@ -45,7 +45,9 @@ hipError_t exclusive_sum_u32(void *temp, size_t *temp_bytes, const unsigned *in,
 
 namespace {
 
-std::string g_create_error;
+// last error of calls that have no context (icpmi_create, icpmi_load_cloud): per thread, so that
+// contexts created on different threads (slam_icp_adapter.hpp holds one per thread) do not race
+thread_local std::string g_create_error;
 
 struct DevBuf {
     void *p = nullptr;
@@ -251,7 +253,7 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
              *perm = keys_in + 3 * (size_t)m;
     hipStream_t s = ctx->stream;
     StageTimer t(ctx, ST_SETUP);
-    hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_tgt, m, (double *)ctx->bbox_part.p);
+    hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_tgt, m, (double *)ctx->bbox_part.p, 1);
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, frame);
     hipLaunchKernelGGL(k_morton_keys, dim3((m + 255) / 256), dim3(256), 0, s, d_tgt, m, (const NnFrame *)frame,
                        keys_in, vals_in);
@@ -600,7 +602,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // together), so that every block of kCoarseQueries consecutive rows of `cur` is a compact
     // blob whose bounding box can rule whole target splits out.  The order of the rows of
     // `cur` is internal: only sums over all rows leave this function.
-    const bool pruned = fused && ctx->nn_pruned;
+    const bool pruned = fused && ctx->nn_pruned && n > 0;
     const int qblocks = (n + kCoarseQueries - 1) / kCoarseQueries;
     int *blk_cnt = nullptr, *blk_list = nullptr;
     unsigned *work = nullptr, *work_cnt = nullptr;
@@ -626,7 +628,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         unsigned *keys_in = (unsigned *)ctx->src_sort.p, *keys_out = keys_in + n, *vals_in = keys_in + 2 * (size_t)n,
                  *perm = keys_in + 3 * (size_t)n;
         StageTimer t(ctx, ST_SETUP);
-        hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_src, n, (double *)ctx->bbox_part.p);
+        hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_src, n, (double *)ctx->bbox_part.p, 1);
         hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, sframe);
         hipLaunchKernelGGL(k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, (const NnFrame *)sframe,
                            keys_in, vals_in);
@@ -635,7 +637,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     }
 
     // current_source = source * R0^T + t0^T (icp.hpp:174-176)
-    {
+    if (n > 0) { // (an empty shard of a sharded run launches nothing over its rows)
         StageTimer t(ctx, ST_TRANSFORM);
         if (pruned)
             hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, d_src, src_perm, cur, n,
@@ -648,11 +650,11 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
 
     auto iteration = [&](int final_pass, int *progress, int ticket) -> int {
         int r2;
-        if (fused) {
+        if (n > 0 && fused) {
             if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, ctx->d_state, d_tgt, nrm, partials,
                                      pruned ? pass_no : -1))) return r2;
             ++pass_no;
-        } else {
+        } else if (n > 0) {
             if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, ctx->d_state))) return r2;
         }
         {
@@ -663,14 +665,15 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
             if (sharded) {
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
                                    ctx->d_state);
-                if ((r2 = exchange_allreduce(ctx, ctx->d_state->sums, kNumSums))) return r2;
-                hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, ctx->d_state, hist, final_pass, progress, ticket);
+                if ((r2 = exchange_allreduce(ctx, ctx->d_state->sums, kNumExchanged))) return r2;
+                hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, ctx->d_state, hist, final_pass, progress, ticket,
+                                   ctx->n_ranks);
             } else {
                 hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
                                    ctx->d_state, hist, final_pass, progress, ticket);
             }
         }
-        if (!final_pass) {
+        if (!final_pass && n > 0) {
             StageTimer t(ctx, ST_TRANSFORM);
             if (pruned) // + each block's box and its exact distance bound to this iteration's neighbours
                 hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, (const double *)cur,
@@ -723,6 +726,9 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         HIP_TRY(ctx, hipMemcpy(error_history, hist, sizeof(double) * (size_t)std::min(hl, history_cap),
                                hipMemcpyDeviceToHost));
     harvest_profile(ctx);
+    if (hs->error)
+        return fail(ctx, ICPMI_ERR_RCCL, "the ranks of this sharded run disagreed on the end of the loop "
+                                         "(different icpmi_config per rank, or an exchange that is not bit-identical on every rank)");
 
     memcpy(result->transformation, hs->total, sizeof(double) * 16); // icp.hpp:254
     result->converged = hs->converged;
@@ -751,7 +757,7 @@ int voxel_downsample_device(icpmi_ctx *ctx, const double *d_pts, int n, double v
     if ((rc = reserve(ctx, ctx->bbox_part, sizeof(double) * 6 * (size_t)bblocks))) return rc;
     if ((rc = reserve(ctx, ctx->nn_misc, 256))) return rc;
     NnFrame *frame = (NnFrame *)ctx->nn_misc.p;
-    hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_pts, n, (double *)ctx->bbox_part.p);
+    hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_pts, n, (double *)ctx->bbox_part.p, 0);
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, frame);
     NnFrame hf;
     HIP_TRY(ctx, hipMemcpyAsync(&hf, frame, sizeof(NnFrame), hipMemcpyDeviceToHost, s));
@@ -797,8 +803,11 @@ int validate_align(icpmi_ctx *ctx, const void *src, int64_t n_src, const void *t
                    const icpmi_config *cfg, icpmi_result *result, double *hist, int32_t cap)
 {
     if (!ctx) return ICPMI_ERR_NULL;
-    if (!src || !tgt || !cfg || !result || !hist) return fail(ctx, ICPMI_ERR_NULL, "null argument");
-    if (n_src <= 0) return fail(ctx, ICPMI_ERR_EMPTY_SOURCE, "empty source cloud");
+    if (!tgt || !cfg || !result || !hist || (!src && n_src != 0)) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    // a rank of a sharded run may hold an empty shard (fewer source points than ranks, uneven
+    // sharding): it contributes zero sums and a zero count and takes part in every exchange
+    const bool may_be_empty = ctx->n_ranks > 1 && (ctx->comm != nullptr || ctx->cb_allreduce != nullptr);
+    if (n_src < 0 || (n_src == 0 && !may_be_empty)) return fail(ctx, ICPMI_ERR_EMPTY_SOURCE, "empty source cloud");
     if (n_tgt <= 0) return fail(ctx, ICPMI_ERR_EMPTY_TARGET, "empty target cloud");
     if (n_src > (int64_t)700000000 || n_tgt > (int64_t)700000000)
         return fail(ctx, ICPMI_ERR_ARG, "cloud larger than 7e8 points");

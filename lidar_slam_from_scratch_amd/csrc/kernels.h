@@ -22,6 +22,11 @@ namespace icpmi {
 constexpr int kWave = 64;
 constexpr int kNumSums = 29;       // 21 JtJ (upper, row by row) + 6 Jtb + sum b^2 + count
 constexpr int kSumsStride = 32;
+// Sharded runs all-reduce one more word: sums[kDoneSlot] = 1 on a rank whose loop has ended.
+// Small integers add exactly in any order, so every rank reads the same count whatever the
+// collective's algorithm: the hosts stop queueing iterations on that agreed count alone.
+constexpr int kDoneSlot = 29;
+constexpr int kNumExchanged = 30;
 
 struct IcpState {
     double total[16];       // accumulated source->target transform (icp.hpp:178,229)
@@ -37,7 +42,7 @@ struct IcpState {
     int32_t converged;
     int32_t loops;
     int32_t max_hist;
-    int32_t pad;
+    int32_t error;          // sharded runs: the ranks disagreed on `done` (k_step)
 };
 
 // ------------------------------------------------------------------------------------
@@ -260,9 +265,9 @@ __device__ inline void step_update(IcpState *st, double *history, int final_pass
 // `progress` (may be null) is one word of host-mapped memory per iteration slot: the device
 // publishes (iteration + 1) * 2 + done there, so the host can stop queueing iterations
 // without any copy or event in the stream.
-__device__ __forceinline__ void publish_progress(int *progress, int ticket, const IcpState *st)
+__device__ __forceinline__ void publish_progress(int *progress, int ticket, int done)
 {
-    if (progress) __hip_atomic_store(progress, ticket * 2 + (st->done ? 1 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (progress) __hip_atomic_store(progress, ticket * 2 + (done ? 1 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // The state is staged in LDS for the serial part: step_update touches ~100 of its words one
@@ -287,32 +292,47 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step(const double *__
     __syncthreads();
     if (threadIdx.x == 0) {
         step_update(&ls, history, final_pass);
-        publish_progress(progress, ticket, &ls);
+        publish_progress(progress, ticket, ls.done);
     }
     __syncthreads();
     state_copy(st, &ls);
 }
 
-// multi GPU: k_finish -> ncclAllReduce(st->sums, 29) -> k_step
+// multi GPU: k_finish -> ncclAllReduce(st->sums, kNumExchanged) -> k_step
 __global__ __launch_bounds__(kFinishThreads) void k_finish(const double *__restrict__ partials, int nblocks,
                                                 int n_local, IcpState *st)
 {
     if (st->done) {
         // keep the all-reduce operands finite and identical on every rank
         if (threadIdx.x < kNumSums) st->sums[threadIdx.x] = 0.0;
+        if (threadIdx.x == 0) st->sums[kDoneSlot] = 1.0;
         return;
     }
     finish_sums(partials, nblocks, n_local, st);
+    if (threadIdx.x == 0) st->sums[kDoneSlot] = 0.0;
 }
 
-__global__ __launch_bounds__(64) void k_step(IcpState *st, double *history, int final_pass, int *progress, int ticket)
+// The word published to the host carries the AGREED end of the loop: the number of ranks that
+// entered this iteration with `done` set (decided one step earlier) came through the exchange
+// as an exact integer.  All of them: the loop has ended everywhere, the hosts stop queueing at
+// the same iteration and therefore queue the same number of collectives.  Some but not all
+// (differing configs, or an all-reduce that did not hand every rank the same bits): every rank
+// sees the same count, flags the error and ends its loop at this same iteration.
+__global__ __launch_bounds__(64) void k_step(IcpState *st, double *history, int final_pass, int *progress, int ticket,
+                                             int n_ranks)
 {
     __shared__ IcpState ls;
     state_copy(&ls, st);
     __syncthreads();
     if (threadIdx.x == 0) {
+        const double ndone = ls.sums[kDoneSlot];
+        const bool all = ndone == (double)n_ranks, some = ndone > 0.0 && !all;
+        if (some) {
+            ls.error = 1;
+            ls.done = 1;
+        }
         step_update(&ls, history, final_pass);
-        publish_progress(progress, ticket, &ls);
+        publish_progress(progress, ticket, all || some);
     }
     __syncthreads();
     state_copy(st, &ls);

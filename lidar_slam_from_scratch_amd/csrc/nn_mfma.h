@@ -103,16 +103,28 @@ struct BlockBounds {
 };
 
 // ---- bounding box -----------------------------------------------------------------------------
+// A target with a non-finite coordinate is never anybody's nearest neighbour (kdtree.hpp:125: no
+// `dist_sq < best` holds for an infinite or NaN distance), so the search structures are built
+// from the finite targets only (`finite_only`): boxes, centres and radii stay finite, and such
+// a target is packed as padding.  The voxel filter keeps every point in its box (and then
+// rejects a non-finite one).
+__device__ __forceinline__ bool finite3(double x, double y, double z)
+{
+    return __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
+}
+
 __global__ __launch_bounds__(256) void k_bbox_partial(const double *__restrict__ pts, int m,
-                                                      double *__restrict__ part /*[grid][6]*/)
+                                                      double *__restrict__ part /*[grid][6]*/, int finite_only)
 {
     double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+        if (finite_only && !finite3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2])) continue;
         for (int a = 0; a < 3; ++a) {
             const double v = pts[3 * i + a];
             lo[a] = v < lo[a] ? v : lo[a];
             hi[a] = v > hi[a] ? v : hi[a];
         }
+    }
     __shared__ double red[4][6];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int a = 0; a < 3; ++a) {
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(256) void k_morton_keys(const double *__restrict__ 
     unsigned q[3];
     for (int a = 0; a < 3; ++a) {
         double f = ext > 0.0 ? (pts[3 * i + a] - frame->lo[a]) / ext : 0.0;
-        f = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
+        f = !(f >= 0.0) ? 0.0 : (f > 1.0 ? 1.0 : f); // (a NaN coordinate sorts with the low corner)
         const int qi = (int)(f * 1023.0);
         q[a] = (unsigned)(qi < 0 ? 0 : (qi > 1023 ? 1023 : qi));
     }
@@ -204,12 +216,14 @@ __global__ __launch_bounds__(256) void k_split_frames(const double *__restrict__
     const int s = blockIdx.x;
     const int j0 = s * kSplitTargets, j1 = min(m, j0 + kSplitTargets);
     double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
-    for (int j = j0 + threadIdx.x; j < j1; j += 256)
+    for (int j = j0 + threadIdx.x; j < j1; j += 256) {
+        if (!finite3(ICPMI_SX(sorted, ms, j), ICPMI_SY(sorted, ms, j), ICPMI_SZ(sorted, ms, j))) continue;
         for (int a = 0; a < 3; ++a) {
             const double v = sorted[(size_t)a * ms + j];
             lo[a] = v < lo[a] ? v : lo[a];
             hi[a] = v > hi[a] ? v : hi[a];
         }
+    }
     __shared__ double red[4][6];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int a = 0; a < 3; ++a) {
@@ -233,10 +247,11 @@ __global__ __launch_bounds__(256) void k_split_frames(const double *__restrict__
                 l = red[w][a] < l ? red[w][a] : l;
                 h = red[w][3 + a] > h ? red[w][3 + a] : h;
             }
-            frames[s].c[a] = 0.5 * (l + h);
-            frames[s].lo[a] = l;
+            const bool empty = l > h; // no finite target in this split: everything in it is padding
+            frames[s].c[a] = empty ? 0.0 : 0.5 * (l + h);
+            frames[s].lo[a] = l;      // (an empty box is infinitely far from every block: always culled)
             frames[s].hi[a] = h;
-            const double half = 0.5 * (h - l);
+            const double half = empty ? 0.0 : 0.5 * (h - l);
             h2 += half * half;
         }
         frames[s].rho = sqrt(h2) * (1.0 + 1e-6) + 1e-300;
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(256) void k_pack_targets(const double *__restrict__
     const int col = lane & 31, half = lane >> 5;
     const long j = (long)s * kSplitTargets + col * kSlotTargets + t;
     unsigned piece[3][2], np[3];
-    if (j < m) {
+    if (j < m && finite3(ICPMI_SX(sorted, ms, j), ICPMI_SY(sorted, ms, j), ICPMI_SZ(sorted, ms, j))) {
         double n2 = 0.0;
         for (int a = 0; a < 3; ++a) {
             const float q = (float)(sorted[(size_t)a * ms + j] - frames[s].c[a]);
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(256) void k_pack_targets(const double *__restrict__
             n2 += qt * qt;
         }
         split3((float)n2, np[0], np[1], np[2]);
-    } else { // padding: never the minimum
+    } else { // padding (past the end, or a non-finite target): never the minimum
         for (int a = 0; a < 3; ++a) piece[a][0] = piece[a][1] = 0u;
         split3(kBig, np[0], np[1], np[2]);
     }
@@ -733,6 +748,7 @@ __device__ __forceinline__ float split_tau(double px, double py, double pz, cons
     const double eps = kReprEps * a * (1.0 + 1e-6);
     double tau = d + eps * (2.0 * sqrt_d + eps) + kArithBound * u * a * a;
     tau = tau * (1.0 + 4e-6) + 1e-300; // column tag (2^-20) + slack for this fp64 evaluation
+    if (!(tau < 3.0e38)) return 3.4028235e38f; // beyond fp32 (or NaN): every recorded value is inside the bound
     return __uint_as_float(__float_as_uint((float)tau) + 1u); // round up (tau > 0)
 }
 
@@ -1308,7 +1324,8 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             dloc[c] = kInf;
             oloc[c] = 0;
             if (jj < m) {
-                dloc[c] = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), px, py, pz);
+                const double d = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), px, py, pz);
+                dloc[c] = d == d ? d : kInf; // a NaN would break the order the sort below relies on
                 oloc[c] = (int)perm[jj];
             }
         }

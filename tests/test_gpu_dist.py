@@ -22,6 +22,54 @@ def _free_port():
     return p
 
 
+def _worker_uneven(rank, world, port, out_dir, npts, search):
+    """Rank 1 of 3 holds an EMPTY shard (it used to return ICPMI_ERR_EMPTY_SOURCE and
+    leave the others waiting in the all-gather); rank 2 runs with a different tolerance in the
+    second call, which the agreed-done word must turn into an error on EVERY rank, not a hang."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from lidar_slam_from_scratch_amd import capi, dist as icpdist, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    src, tgt, _ = synth.c1_room_corner(npts)
+    cut = [0, npts // 2, npts // 2, npts]
+    mine = src[cut[rank]:cut[rank + 1]]
+    ctx = capi.Context(device=0, search=search)
+    icpdist.init_callbacks(ctx, dist)
+    res, hist = ctx.align(mine, tgt, capi.Context.make_config())
+    out = dict(T=np.array(res.transformation[:]).reshape(4, 4), hist=hist, conv=res.converged,
+               iters=res.num_iterations, rows=mine.shape[0])
+    # second call: the ranks are given different stopping rules
+    tol = 1e-6 if rank != 2 else 1e-2
+    try:
+        ctx.align(mine, tgt, capi.Context.make_config(tolerance=tol))
+        out["second"] = "ok"
+    except capi.IcpError as e:
+        out["second"] = "error %d" % e.code
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
+    ctx.comm_finalize()
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_empty_shard_and_disagreeing_ranks(tmp_path, oracle):
+    from lidar_slam_from_scratch_amd import capi, synth
+    npts, world = 3000, 3
+    mp.spawn(_worker_uneven, args=(world, _free_port(), str(tmp_path), npts, capi.SEARCH_AUTO), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(world)]
+    assert [int(x["rows"]) for x in r] == [1500, 0, 1500]
+    for k in range(1, world):
+        assert (r[0]["T"] == r[k]["T"]).all() and (r[0]["hist"] == r[k]["hist"]).all()
+    src, tgt, _ = synth.c1_room_corner(npts)
+    ref = oracle.icp_point_to_plane(src, tgt)
+    assert int(r[0]["iters"]) == ref.num_iterations and bool(r[0]["conv"]) == ref.converged
+    np.testing.assert_allclose(r[0]["hist"], ref.error_history, atol=1e-9)
+    # rank 2's looser tolerance ends its loop earlier: every rank reports it (ICPMI_ERR_RCCL = -6)
+    assert [str(x["second"]) for x in r] == ["error -6"] * world
+
+
 def _worker(rank, world, port, out_dir, npts=3001, search=0):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist

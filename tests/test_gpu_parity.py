@@ -546,6 +546,30 @@ def test_nonfinite_input_is_memory_safe(gpu_ctx):
     assert np.isfinite(res.final_error)                 # the context still works
 
 
+def test_nonfinite_targets_are_never_neighbours(gpu_ctx, oracle):
+    """A target with an Inf or NaN coordinate has no finite distance to anything, so no
+    `dist_sq < best` (kdtree.hpp:125) ever selects it: every engine must return the nearest of
+    the FINITE targets, bit for bit what the exhaustive oracle returns on the same array.
+    (an Inf target used to turn its whole 2048-target split into NaN columns.)"""
+    src, tgt, _ = synth.c3_uniform(12000, seed=61, perm_seed=62)
+    tbad = tgt.copy()
+    tbad[17, 0] = np.inf
+    tbad[4000, 2] = -np.inf
+    tbad[4001] = np.nan
+    tbad[9000:9003, 1] = np.inf        # three in one slot
+    tbad[11999, 0] = np.nan
+    idx, d2 = gpu_ctx.nearest_batch(tbad, src)
+    oidx, od2 = oracle.nearest_batch_brute(tbad, src)
+    assert (idx == oidx).all() and (d2 == od2).all()
+    bad_rows = np.flatnonzero(~np.isfinite(tbad).all(axis=1))
+    assert not np.isin(idx, bad_rows).any()
+    # a query far outside the cloud (squared distance beyond fp32): the bound must saturate, not turn NaN
+    far = np.array([[1e25, -1e25, 3e24], [0.0, 0.0, 0.0]])
+    fi, fd = gpu_ctx.nearest_batch(tbad, far)
+    oi, od = oracle.nearest_batch_brute(tbad, far)
+    assert (fi == oi).all() and (fd == od).all()
+
+
 def test_profile_counters(gpu_ctx):
     src, tgt, _ = synth.c1_room_corner(2000)
     gpu_ctx.reset_profile()
