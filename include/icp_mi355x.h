@@ -127,6 +127,16 @@ int icpmi_nearest_batch(icpmi_ctx *ctx, const double *targets_xyz, int64_t n_tgt
                         const double *queries_xyz, int64_t n_qry, int32_t *indices,
                         double *dist_sq);
 
+/* Replaces KDTree::k_nearest (kdtree.hpp:65-78) for a batch of query points: indices (n_qry x k,
+ * row-major) of the k nearest targets of every query, closest first as kdtree.hpp:72-76 returns
+ * them; equal distances in ascending index order.  A target used as a query finds itself
+ * first (distance 0), like the reference.  1 <= k <= 64.  Entries a list does not reach
+ * (k > n_tgt; a query with a NaN coordinate) are -1 with distance +infinity.  dist_sq (n_qry x
+ * k) may be NULL.  Host pointers. */
+int icpmi_k_nearest(icpmi_ctx *ctx, const double *targets_xyz, int64_t n_tgt,
+                    const double *queries_xyz, int64_t n_qry, int32_t k, int32_t *indices,
+                    double *dist_sq);
+
 /* Replaces estimate_normals(points, tree, k) (icp.hpp:23-67).  Host pointers. */
 int icpmi_estimate_normals(icpmi_ctx *ctx, const double *points_xyz, int64_t n, int32_t k,
                            double *normals_xyz);

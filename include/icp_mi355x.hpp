@@ -267,6 +267,18 @@ public:
         nearest_batch(PointCloud(query.data(), 1), i, d);
         return {i[0], d[0]};
     }
+    // kdtree.hpp:65-78: indices of the k nearest rows to one point, closest first
+    std::vector<int> k_nearest(const std::array<double, 3> &query, int k) const
+    {
+        std::vector<int32_t> idx(static_cast<std::size_t>(k > 0 ? k : 0), -1);
+        Context &c = ctx_ ? *ctx_ : default_context();
+        int rc = icpmi_k_nearest(c.get(), pts_.data(), static_cast<int64_t>(pts_.size()), query.data(), 1, k, idx.data(), nullptr);
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(c.get()));
+        std::vector<int> out;
+        for (int32_t j : idx)
+            if (j >= 0) out.push_back(j);
+        return out;
+    }
 
 private:
     PointCloud pts_;

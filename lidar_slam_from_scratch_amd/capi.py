@@ -19,7 +19,7 @@ UNIQUE_ID_BYTES = 128
 EXPORTS = [
     "icpmi_version", "icpmi_options_default", "icpmi_config_default", "icpmi_create",
     "icpmi_destroy", "icpmi_last_error", "icpmi_align", "icpmi_align_device",
-    "icpmi_nearest_batch", "icpmi_estimate_normals", "icpmi_solve_point_to_plane",
+    "icpmi_nearest_batch", "icpmi_k_nearest", "icpmi_estimate_normals", "icpmi_solve_point_to_plane",
     "icpmi_transform_points", "icpmi_comm_unique_id", "icpmi_comm_init", "icpmi_comm_finalize",
     "icpmi_comm_init_callbacks", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
     "icpmi_scan_context", "icpmi_scan_context_distances", "icpmi_load_cloud",
@@ -137,6 +137,7 @@ def load_library(path=None):
     L.icpmi_align_device.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.POINTER(Config),
                                      C.POINTER(Result), dp, C.c_int32]
     L.icpmi_nearest_batch.argtypes = [vp, dp, C.c_int64, dp, C.c_int64, C.POINTER(C.c_int32), dp]
+    L.icpmi_k_nearest.argtypes = [vp, dp, C.c_int64, dp, C.c_int64, C.c_int32, C.POINTER(C.c_int32), dp]
     L.icpmi_estimate_normals.argtypes = [vp, dp, C.c_int64, C.c_int32, dp]
     L.icpmi_solve_point_to_plane.argtypes = [vp, dp, dp, dp, C.c_int64, dp]
     L.icpmi_transform_points.argtypes = [vp, dp, dp, C.c_int64, dp]
@@ -243,6 +244,16 @@ class Context:
         d2 = np.empty(qry.shape[0]) if want_dist else None
         self._check(self._lib.icpmi_nearest_batch(
             self._h, _dp(tgt), tgt.shape[0], _dp(qry), qry.shape[0],
+            idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(d2) if want_dist else None))
+        return idx, d2
+
+    def k_nearest(self, targets, queries, k, want_dist=True):
+        """kdtree.hpp:65-78 for a batch of queries -> (indices n x k closest first, squared distances)"""
+        tgt, qry = _f64(targets), _f64(queries)
+        idx = np.empty((qry.shape[0], k), dtype=np.int32)
+        d2 = np.empty((qry.shape[0], k)) if want_dist else None
+        self._check(self._lib.icpmi_k_nearest(
+            self._h, _dp(tgt), tgt.shape[0], _dp(qry), qry.shape[0], k,
             idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(d2) if want_dist else None))
         return idx, d2
 

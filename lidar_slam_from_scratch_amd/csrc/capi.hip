@@ -61,6 +61,40 @@ struct EventPair {
 
 enum Stage { ST_NN = 0, ST_REDUCE = 1, ST_TRANSFORM = 2, ST_NORMALS = 3, ST_TOTAL = 4, ST_LOOP = 5, ST_SETUP = 6, ST_COARSE = 7 };
 
+// roctx ranges around the stages of a call (SURVEY section 5 "Tracing"): visible to
+// `rocprofv3 --marker-trace`.  The library is looked up at run time -- libroctx64 is whichever
+// copy the process already has (torch bundles one) or the ROCm one -- and a missing one only
+// means no ranges.  Costs two indirect calls per stage when nothing listens.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *names[] = {"libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so.4",
+                               "librocprofiler-sdk-roctx.so.1"};
+        for (const char *nm : names) {
+            void *lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (!lib) continue;
+            push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr;
+            pop = nullptr;
+        }
+    }
+};
+const Roctx &roctx()
+{
+    static Roctx r;
+    return r;
+}
+struct Range { // RAII: one roctx range
+    explicit Range(const char *name) { if (roctx().push) roctx().push(name); }
+    ~Range() { if (roctx().pop) roctx().pop(); }
+    Range(const Range &) = delete;
+    Range &operator=(const Range &) = delete;
+};
+
 struct Rccl {
     void *lib = nullptr;
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
@@ -252,6 +286,7 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     unsigned *keys_in = (unsigned *)ctx->sort_keys.p, *keys_out = keys_in + m, *vals_in = keys_in + 2 * (size_t)m,
              *perm = keys_in + 3 * (size_t)m;
     hipStream_t s = ctx->stream;
+    Range range("icpmi:target_prepass");
     StageTimer t(ctx, ST_SETUP);
     hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_tgt, m, (double *)ctx->bbox_part.p, 1);
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, frame);
@@ -302,6 +337,7 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     const SplitFrame *frames = (const SplitFrame *)ctx->frames.p;
     const unsigned *perm = (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m;
     unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);
+    Range range("icpmi:nn_search");
     StageTimer t(ctx, ST_NN);
     {
         StageTimer tc(ctx, ST_COARSE); // the dominant kernel alone (matches rocprofv3's per-kernel average)
@@ -325,7 +361,7 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     const int *blk_list = blk_cnt ? blk_cnt + (n + kCoarseQueries - 1) / kCoarseQueries : nullptr;
 #define ICPMI_RESOLVE_ARGS                                                                                            \
     d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits, frames,  \
-        d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, blk_cnt, blk_list, st
+        (const NnFrame *)ctx->nn_misc.p, d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, blk_cnt, blk_list, st
     switch (resolve_waves(n)) {
     case 0: hipLaunchKernelGGL(k_nn_resolve, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     case 4: hipLaunchKernelGGL(k_nn_resolve4<4>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
@@ -353,6 +389,7 @@ int launch_nn(icpmi_ctx *ctx, const double *d_qry, int n, const double *d_tgt, i
     int rc;
     if ((rc = reserve(ctx, ctx->part_d2, sizeof(double) * (size_t)splits * n))) return rc;
     if ((rc = reserve(ctx, ctx->part_idx, sizeof(int) * (size_t)splits * n))) return rc;
+    Range range("icpmi:nn_search");
     StageTimer t(ctx, ST_NN);
     hipLaunchKernelGGL(k_nn_f64<QPT>, dim3(qblocks, splits), dim3(256), 0, ctx->stream, d_qry, n,
                        d_tgt, m, per, (double *)ctx->part_d2.p, (int *)ctx->part_idx.p, st);
@@ -369,27 +406,26 @@ int reduce_blocks(const icpmi_ctx *ctx, int n)
     return std::max(1, std::min(ctx->cu_count, (n + 255) / 256));
 }
 
-// normals of rows [row0,row1) of d_pts against all m points (icp.hpp:23-67): k-NN lists
-// (MFMA coarse + exact resolve, or the exact fp64 kernel) then PCA.  prepare_nn() must have
-// run for d_pts.
-// With the pruned engine (`by_sorted_row`), [row0, row1) are positions in the Morton-sorted
-// target (row0 a multiple of 64) and `scatter` selects where a normal goes: to its point's row
-// of d_normals (m rows), or to its sorted row (what a rank contributes to the all-gather).
-int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, int row1,
-                   double *d_normals, bool by_sorted_row = false, bool scatter = true)
+// k-NN lists of rows [row0,row1) of d_qry among the m points d_pts (kdtree.hpp:65-78): MFMA
+// coarse pass + exact resolve, or the exact fp64 kernel.  List of row i -> ctx->knn_idx[i * k ..],
+// closest first.  prepare_nn() must have run for d_pts.  d_qry == d_pts for normal estimation.
+// With the pruned engine (`by_sorted_row`, d_qry == d_pts only), [row0, row1) are positions in the
+// Morton-sorted target (row0 a multiple of 64).
+int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *d_pts, int m, int k, int row0, int row1,
+               bool by_sorted_row = false)
 {
     const int rows = row1 - row0;
     if (rows <= 0) return ICPMI_OK;
     int rc;
-    if ((rc = reserve(ctx, ctx->knn_idx, sizeof(int) * (size_t)m * k))) return rc;
+    if ((rc = reserve(ctx, ctx->knn_idx, sizeof(int) * (size_t)std::max(m, nq_total) * k))) return rc;
     int *knn = (int *)ctx->knn_idx.p;
     hipStream_t s = ctx->stream;
     constexpr int BLOCK = 128;
     const size_t smem = (size_t)k * BLOCK * (sizeof(double) + sizeof(int));
     const bool mfma = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= 4 * kSplitTargets;
     const unsigned *perm = mfma ? (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m : nullptr;
-    if (by_sorted_row && !mfma) return fail(ctx, ICPMI_ERR_ARG, "sorted-row normals need the MFMA engine's sorted target");
-    StageTimer t(ctx, ST_NORMALS);
+    const double *qsep = d_qry == d_pts ? nullptr : d_qry; // the exact kernels read rows from d_pts unless told otherwise
+    if (by_sorted_row && (!mfma || qsep)) return fail(ctx, ICPMI_ERR_ARG, "sorted-row lists need the MFMA engine's sorted target");
     if (mfma) {
         const int splits = ctx->nn_splits, nslots = splits * kCols;
         // bound the slot-minimum buffer (4 B x nslots per row) by chunking the rows: ~1 GiB, or
@@ -431,16 +467,16 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
                                    (const int *)blk_cnt, (const int *)blk_list);
             } else {
                 hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves>), dim3(nblk, splits),
-                                   dim3(kCoarseThreads), 0, s, d_pts + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
+                                   dim3(kCoarseThreads), 0, s, d_qry + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
                                    frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
-                hipLaunchKernelGGL(k_knn_resolve<false>, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq, sorted, perm, m,
+                hipLaunchKernelGGL(k_knn_resolve<false>, dim3((nq + 3) / 4), dim3(256), 0, s, d_qry, (int)c0, nq, sorted, perm, m,
                                    ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots, frames, knn, fb_list, fb_count,
                                    (const int *)nullptr, (const int *)nullptr);
             }
         }
         hipLaunchKernelGGL(k_knn_exact_rows, dim3(1024), dim3(256), (size_t)k * 256 * (sizeof(double) + sizeof(int)),
                            s, d_pts, m, k, (const int *)fb_list, (const int *)fb_count, knn,
-                           by_sorted_row ? perm : (const unsigned *)nullptr);
+                           by_sorted_row ? perm : (const unsigned *)nullptr, qsep);
         if (ctx->opt.profile) { // visibility only: how many rows took the exact path
             int cnt = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&cnt, fb_count, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -449,10 +485,29 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
         }
     } else {
         hipLaunchKernelGGL(k_knn_exact_list<BLOCK>, dim3((rows + BLOCK - 1) / BLOCK), dim3(BLOCK), smem, s,
-                           d_pts, m, k, row0, row1, (const int *)nullptr, (const int *)nullptr, knn);
+                           d_pts, m, k, row0, row1, (const int *)nullptr, (const int *)nullptr, knn, qsep);
     }
-    hipLaunchKernelGGL(k_normals_from_knn, dim3((rows + 255) / 256), dim3(256), 0, s, d_pts, m, k, row0, row1,
-                       (const int *)knn, d_normals, by_sorted_row ? perm : (const unsigned *)nullptr,
+    HIP_TRY(ctx, hipGetLastError());
+    return ICPMI_OK;
+}
+
+// normals of rows [row0,row1) of d_pts against all m points (icp.hpp:23-67): k-NN lists then PCA.
+// With the pruned engine (`by_sorted_row`) the rows are sorted positions and `scatter` selects
+// where a normal goes: to its point's row of d_normals (m rows), or to its sorted row (what a
+// rank contributes to the all-gather).
+int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, int row1,
+                   double *d_normals, bool by_sorted_row = false, bool scatter = true)
+{
+    const int rows = row1 - row0;
+    if (rows <= 0) return ICPMI_OK;
+    int rc;
+    Range range("icpmi:normals");
+    StageTimer t(ctx, ST_NORMALS);
+    if ((rc = launch_knn(ctx, d_pts, m, d_pts, m, k, row0, row1, by_sorted_row))) return rc;
+    const bool mfma = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= 4 * kSplitTargets;
+    const unsigned *perm = mfma ? (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m : nullptr;
+    hipLaunchKernelGGL(k_normals_from_knn, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, d_pts, m, k, row0, row1,
+                       (const int *)ctx->knn_idx.p, d_normals, by_sorted_row ? perm : (const unsigned *)nullptr,
                        (int)(by_sorted_row && scatter));
     HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;
@@ -553,6 +608,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     int *idx = (int *)ctx->idx.p;
     double *hist = (double *)ctx->history.p;
 
+    Range range_call("icpmi:align");
     StageTimer *t_total = new StageTimer(ctx, ST_TOTAL);
     struct Closer { StageTimer *&p; ~Closer() { delete p; p = nullptr; } } close_total{t_total};
 
@@ -658,6 +714,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
             if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, ctx->d_state))) return r2;
         }
         {
+            Range range("icpmi:reduce_solve");
             StageTimer t(ctx, ST_REDUCE);
             if (!fused)
                 hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, cur, n, d_tgt, m, nrm, idx, partials,
@@ -674,6 +731,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
             }
         }
         if (!final_pass && n > 0) {
+            Range range("icpmi:transform");
             StageTimer t(ctx, ST_TRANSFORM);
             if (pruned) // + each block's box and its exact distance bound to this iteration's neighbours
                 hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, (const double *)cur,
@@ -687,6 +745,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         return ICPMI_OK;
     };
 
+    Range range_loop("icpmi:icp_loop");
     StageTimer *t_loop = new StageTimer(ctx, ST_LOOP);
     struct Closer2 { StageTimer *&p; ~Closer2() { delete p; p = nullptr; } } close_loop{t_loop};
     for (int i = 0; i < kFlagRing; ++i) ctx->h_flags[i] = 0;
@@ -1002,6 +1061,44 @@ int icpmi_estimate_normals(icpmi_ctx *ctx, const double *points_xyz, int64_t n, 
     if ((rc = launch_normals(ctx, (const double *)ctx->stage_c.p, m, k, 0, m, (double *)ctx->nrm.p, sorted_rows, true))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(normals_xyz, ctx->nrm.p, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    harvest_profile(ctx);
+    return ICPMI_OK;
+}
+
+int icpmi_k_nearest(icpmi_ctx *ctx, const double *targets_xyz, int64_t n_tgt, const double *queries_xyz,
+                    int64_t n_qry, int32_t k, int32_t *indices, double *dist_sq)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!targets_xyz || !queries_xyz || !indices) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n_tgt <= 0) return fail(ctx, ICPMI_ERR_EMPTY_TARGET, "empty target cloud");
+    if (n_qry < 0) return fail(ctx, ICPMI_ERR_ARG, "n_qry < 0");
+    if (k < 1 || k > 64) return fail(ctx, ICPMI_ERR_ARG, "k %d outside [1,64]", k);
+    if (n_qry > (int64_t)30000000 || n_tgt > (int64_t)700000000) return fail(ctx, ICPMI_ERR_ARG, "cloud too large");
+    if (n_qry == 0) return ICPMI_OK;
+    const int n = (int)n_qry, m = (int)n_tgt;
+    if ((rc = reserve(ctx, ctx->stage_b, sizeof(double) * 3 * (size_t)n))) return rc;
+    if ((rc = reserve(ctx, ctx->stage_c, sizeof(double) * 3 * (size_t)m))) return rc;
+    if ((rc = reserve(ctx, ctx->knn_idx, sizeof(int) * (size_t)std::max(m, n) * k))) return rc;
+    if (dist_sq && (rc = reserve(ctx, ctx->d2out, sizeof(double) * (size_t)n * k))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_b.p, queries_xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.p, targets_xyz, sizeof(double) * 3 * (size_t)m, hipMemcpyHostToDevice, s));
+    // entries a list does not reach (k > n_tgt, a query with a NaN coordinate) stay -1 / +infinity
+    HIP_TRY(ctx, hipMemsetAsync(ctx->knn_idx.p, 0xFF, sizeof(int) * (size_t)n * k, s));
+    if ((rc = prepare_nn(ctx, (const double *)ctx->stage_c.p, m, n))) return rc;
+    if ((rc = launch_knn(ctx, (const double *)ctx->stage_b.p, n, (const double *)ctx->stage_c.p, m, k, 0, n))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(indices, ctx->knn_idx.p, sizeof(int) * (size_t)n * k, hipMemcpyDeviceToHost, s));
+    if (dist_sq) {
+        for (size_t e = 0; e < (size_t)n * k; ++e) dist_sq[e] = __builtin_inf();
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d2out.p, dist_sq, sizeof(double) * (size_t)n * k, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_knn_distances, dim3((unsigned)(((size_t)n * k + 255) / 256)), dim3(256), 0, s,
+                           (const double *)ctx->stage_b.p, n, (const double *)ctx->stage_c.p, m, k,
+                           (const int *)ctx->knn_idx.p, (double *)ctx->d2out.p);
+        HIP_TRY(ctx, hipMemcpyAsync(dist_sq, ctx->d2out.p, sizeof(double) * (size_t)n * k, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipGetLastError());
     harvest_profile(ctx);
     return ICPMI_OK;
 }

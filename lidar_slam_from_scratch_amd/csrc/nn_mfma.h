@@ -40,8 +40,11 @@
 //   arithmetic: the 15 products are exact; their fp32 accumulation inside the MFMA is not
 //     specified, so every one of the <= 17 additions is charged a full truncation
 //     (2u x the largest magnitude, <= a^2): 34 u a^2; plus fl32(|Q|^2), fl32(|P|^2) formed
-//     with 5 roundings, and the final add: 41 u a^2.  48 u a^2 is used.
-//   column tag: < 2^-19 relative on the stored minimum (inflation 4e-6 covers it).
+//     with 5 roundings, and the final add: 41 u a^2.
+//   column tag (1-NN epilogue): the column number replaces the 5 low mantissa bits of the
+//     contraction BEFORE |P|^2 is added (|contraction| <= |Q|^2 + 2|P||Q| <= a^2: 32 u a^2), the sum
+//     is truncated and tagged again (< 2^-19 relative on the stored minimum: the 4e-6 inflation).
+//   88 u a^2 is used (73 + margin).
 //
 // Engine 3 (ICPMI_SEARCH_MFMA_PRUNED, opt-in) runs the same coarse unit and the same resolve on
 // fewer (query block, split) units: k_transform_bounds / k_knn_block_bounds bound, per block of
@@ -72,7 +75,7 @@ constexpr int kCoarseWaves = 8;                   // waves per workgroup
 constexpr int kCoarseThreads = 64 * kCoarseWaves;
 constexpr int kCoarseQueries = kTile * kCoarseQT * kCoarseWaves; // queries per workgroup
 constexpr float kBig = 3.0e38f;
-constexpr double kArithBound = 48.0;              // x u a^2, see above
+constexpr double kArithBound = 88.0;              // x u a^2, see above
 constexpr double kReprEps = 1.52587890625e-05 + 5.9604644775390625e-08; // 2^-16 + 2^-24
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -332,6 +335,28 @@ __device__ __forceinline__ float min3f(float a, float b, float c)
     return __builtin_fminf(__builtin_fminf(a, b), c); // -> v_min3_f32
 }
 
+// Raw single-instruction forms for the epilogue: the C-level fminf / fmaxf on values that went
+// through integer bit operations make the compiler add a canonicalising v_max_f32 v, v, v in
+// front of every use (it must quiet a signalling NaN it cannot rule out): 16 more VALU per tile.
+// IEEE mode: v_min_f32 returns the other operand for a NaN, v_med3_f32 the minimum of the rest.
+__device__ __forceinline__ float min_raw(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float med3_raw(float a, float b, float c)
+{
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// the 5 low mantissa bits of x replaced by `tag` (< 32): one v_and_or_b32
+__device__ __forceinline__ float tag_low5(float x, unsigned tag)
+{
+    return __uint_as_float((__float_as_uint(x) & 0xFFFFFFE0u) | tag);
+}
+
 // MODE 0: 1-NN epilogue -> coarse[split][n] = (tagged min, second min over the 32 columns)
 // MODE 1: k-NN epilogue  -> slotmin[query][split*32 + column], every column minimum kept
 // QT = 32-query tiles per wave (even); WAVES = waves per workgroup.  (Tried and dropped, see
@@ -439,10 +464,10 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float4 x = rowp[e];
-                v[4 * e] = x.x + pnq;
-                v[4 * e + 1] = x.y + pnq;
-                v[4 * e + 2] = x.z + pnq;
-                v[4 * e + 3] = x.w + pnq;
+                v[4 * e] = x.x;
+                v[4 * e + 1] = x.y;
+                v[4 * e + 2] = x.z;
+                v[4 * e + 3] = x.w;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -451,17 +476,27 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
             if (iq < n) {
                 float4 *dst = reinterpret_cast<float4 *>(slotmin + (size_t)iq * (nsplits * kCols) + s * kCols + half * 16);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dst[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
+                for (int e = 0; e < 4; ++e) // (never above kBig, never NaN: see the 1-NN branch)
+                    dst[e] = make_float4(min_raw(v[4 * e] + pnq, kBig), min_raw(v[4 * e + 1] + pnq, kBig),
+                                         min_raw(v[4 * e + 2] + pnq, kBig), min_raw(v[4 * e + 3] + pnq, kBig));
             }
         } else {
+            // top-2 of this lane's 16 columns on the tagged contraction values (3 VALU per value:
+            // tag, minimum, median = second smallest of {v1 <= v2, x}); |P|^2 is the same for every
+            // column of a query and fl(x + p) is monotone in x, so it is added to the two survivors only
             float v1 = kBig, v2 = kBig;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const float x = __uint_as_float((__float_as_uint(v[c]) & 0xFFFFFFE0u) | (unsigned)(half * 16 + c));
-                const float hi = __builtin_fmaxf(v1, x);
-                v1 = __builtin_fminf(v1, x);
-                v2 = __builtin_fminf(v2, hi);
+                const float x = tag_low5(v[c], (unsigned)c);
+                v2 = med3_raw(v1, v2, x);
+                v1 = min_raw(v1, x);
             }
+            const unsigned col = (__float_as_uint(v1) & 15u) | ((unsigned)half << 4);
+            // a query so far away that its squares overflow fp32 (or with a NaN coordinate) ends up
+            // with +Inf or NaN here: recorded as kBig, which every bound that saturates at FLT_MAX
+            // still covers, so that the resolve falls back to exhaustive scans instead of missing slots
+            v1 = tag_low5(min_raw(__uint_as_float(__float_as_uint(v1) & 0xFFFFFFE0u) + pnq, kBig), col);
+            v2 = min_raw(__uint_as_float(__float_as_uint(v2) & 0xFFFFFFE0u) + pnq, kBig);
             const float o1 = __shfl_xor(v1, 32, 64), o2 = __shfl_xor(v2, 32, 64);
             const float hi = __builtin_fmaxf(v1, o1);
             v1 = __builtin_fminf(v1, o1);
@@ -736,7 +771,21 @@ __global__ __launch_bounds__(kCoarseQueries) void k_knn_block_bounds(
 }
 
 // ---- resolve ---------------------------------------------------------------------------------------
-// bound on the coarse value, in split `f`, of any target whose exact distance is <= d
+__device__ __forceinline__ double px_sel(int a, double x, double y, double z) { return a == 0 ? x : (a == 1 ? y : z); }
+
+// bound on the coarse value of any target whose exact distance is <= d, in a split whose frame
+// term is `a` (>= |p - c_s| + rho_s)
+__device__ __forceinline__ float tau_from_a(double a, double d, double sqrt_d)
+{
+    const double u = 5.9604644775390625e-08; // 2^-24
+    const double eps = kReprEps * a * (1.0 + 1e-6);
+    double tau = d + eps * (2.0 * sqrt_d + eps) + kArithBound * u * a * a;
+    tau = tau * (1.0 + 4e-6) + 1e-300; // column tag (2^-20) + slack for this fp64 evaluation
+    if (!(tau < 3.0e38)) return 3.4028235e38f; // beyond fp32 (or NaN): every recorded value is inside the bound
+    return __uint_as_float(__float_as_uint((float)tau) + 1u); // round up (tau > 0)
+}
+
+// the same bound for split `f`
 __device__ __forceinline__ float split_tau(double px, double py, double pz, const SplitFrame &f, double d,
                                            double sqrt_d)
 {
@@ -744,12 +793,29 @@ __device__ __forceinline__ float split_tau(double px, double py, double pz, cons
     // |p - c| only has to be an upper bound good to ~1e-6: fp32 square root (v_sqrt_f32, 1 ulp;
     // the conversion adds 2^-24) under the 1e-6 inflation instead of a ~35-instruction fp64 one
     const double a = (double)__builtin_amdgcn_sqrtf((float)((dx * dx + dy * dy) + dz * dz)) * (1.0 + 1e-6) + f.rho;
-    const double u = 5.9604644775390625e-08; // 2^-24
-    const double eps = kReprEps * a * (1.0 + 1e-6);
-    double tau = d + eps * (2.0 * sqrt_d + eps) + kArithBound * u * a * a;
-    tau = tau * (1.0 + 4e-6) + 1e-300; // column tag (2^-20) + slack for this fp64 evaluation
-    if (!(tau < 3.0e38)) return 3.4028235e38f; // beyond fp32 (or NaN): every recorded value is inside the bound
-    return __uint_as_float(__float_as_uint((float)tau) + 1u); // round up (tau > 0)
+    return tau_from_a(a, d, sqrt_d);
+}
+
+// ... and one that holds for EVERY split: a split's centre lies inside the bounding box of the
+// whole target (it is the centre of the box of a subset), so |p - c_s| is at most the distance
+// from p to the farthest corner of that box, and rho_s at most its half diagonal.  tau is
+// increasing in a, hence tau_s(d) <= this value for all s: a recorded minimum above it needs
+// no look at its split's frame (the resolve's cheap first filter).
+__device__ __forceinline__ float all_splits_tau(double px, double py, double pz, const NnFrame &g, double d,
+                                                double sqrt_d)
+{
+    double f2 = 0.0, h2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double e1 = fabs(px_sel(a, px, py, pz) - g.lo[a]), e2 = fabs(px_sel(a, px, py, pz) - g.hi[a]);
+        const double e = e1 > e2 ? e1 : e2;
+        f2 += e * e;
+        const double half = 0.5 * (g.hi[a] - g.lo[a]);
+        h2 += half * half;
+    }
+    // (1 + 1e-5): covers the 1e-6 inflations and the fp32 square root on split_tau's side
+    const double a = ((double)__builtin_amdgcn_sqrtf((float)f2) + (double)__builtin_amdgcn_sqrtf((float)h2)) * (1.0 + 1e-5) + 1e-300;
+    return tau_from_a(a, d, sqrt_d);
 }
 
 // wave-wide argmin of (d, j): smaller d, then smaller j; result valid in every lane
@@ -792,6 +858,81 @@ __device__ __forceinline__ void scan_range(const double *__restrict__ sorted,
     }
 }
 
+// Phase 3 of both resolve kernels: the certificate.  A query's list of evaluated splits is
+// shared by GROUP lanes (the 4 quarter-lanes of a query in k_nn_resolve: GROUP = 4, lane offset
+// `sub` = quarter; the 16 lanes of a quarter in k_nn_resolve4: GROUP = 16, sub = ql).  First a
+// cheap pass: one 4-byte load and one compare against all_splits_tau per (query, split), the
+// survivors remembered as bits.  Only they -- the query's own split and the odd neighbour, 1-3
+// of 49 on the 100k cloud -- get the per-split bound (frame loads + ~40 fp64 operations), and
+// the slots or splits under it are scanned exactly by the whole wave.
+template <int GROUP>
+__device__ __forceinline__ void resolve_certify(const int lane, const int sub, const bool valid, const int ic, const int n,
+                                                const double px, const double py, const double pz,
+                                                const float2 *__restrict__ coarse, const int *__restrict__ slist,
+                                                const int nact, const SplitFrame *__restrict__ frames,
+                                                const NnFrame *__restrict__ gframe, const int bs,
+                                                const double *__restrict__ sorted, const unsigned *__restrict__ perm,
+                                                const int m, const int ms, double &bd, int &bj,
+                                                unsigned &extra_slots, unsigned &extra_splits)
+{
+    const double sq = sqrt(bd);
+    const float tmax = all_splits_tau(px, py, pz, *gframe, bd, sq);
+    // a query with a NaN or infinite coordinate has no neighbour whatever is scanned (kdtree.hpp:125
+    // never holds): it takes no part
+    const bool look = valid && finite3(px, py, pz);
+    for (int base = 0; base < nact; base += 32 * GROUP) { // 32 list entries per lane and round
+        unsigned cmask = 0u;
+        const int left = nact - base;
+        const int kmax = left >= 32 * GROUP ? 32 : (left + GROUP - 1) / GROUP; // wave-uniform
+        for (int k = 0; k < kmax; ++k) {
+            const int e = base + k * GROUP + sub;
+            if (e < nact && look) {
+                const int s = slist ? slist[e] : e;
+                cmask |= coarse[(size_t)s * n + ic].x <= tmax ? (1u << k) : 0u;
+            }
+        }
+        while (__ballot(cmask != 0u)) {
+            const bool act = cmask != 0u;
+            const int k = act ? __ffs((int)cmask) - 1 : 0;
+            cmask &= cmask - 1u; // (0 stays 0)
+            int s = 0;
+            bool whole = false, slot = false;
+            float2 v = make_float2(kBig, kBig);
+            if (act) {
+                const int e = base + k * GROUP + sub;
+                s = slist ? slist[e] : e;
+                v = coarse[(size_t)s * n + ic];
+                const float tauf = split_tau(px, py, pz, frames[s], bd, sq);
+                whole = v.y <= tauf;                       // a second column is inside the bound
+                slot = !whole && s != bs && v.x <= tauf;
+            }
+            unsigned long long pend = __ballot(whole || slot);
+            while (pend) {                                 // rare; wave-uniform loop
+                const int L = __ffsll((long long)pend) - 1;
+                pend &= pend - 1;
+                const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
+                const int w = __shfl((int)whole, L, 64);
+                const int c = __shfl((int)(__float_as_uint(v.x) & 31u), L, 64);
+                const int sL = __shfl(s, L, 64);
+                double d = 1.7976931348623157e308;
+                int j = 0x7fffffff;
+                if (w) scan_range(sorted, perm, m, ms, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
+                else scan_range(sorted, perm, m, ms, sL * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
+                // every lane that holds this query takes the result
+                const bool mine = GROUP == 4 ? (lane & 15) == (L & 15) : (lane >> 4) == (L >> 4);
+                if (mine && (d < bd || (d == bd && j < bj))) {
+                    bd = d;
+                    bj = j;
+                }
+                if (lane == L) {
+                    if (w) ++extra_splits;
+                    else ++extra_slots;
+                }
+            }
+        }
+    }
+}
+
 // One wave resolves 16 queries.  Lane = (query ql = lane&15, quarter = lane>>4): the four
 // quarters share the bookkeeping of a query (each looks at a quarter of the splits) and each
 // quarter-wave scans one winning slot at a time (lane ql takes sorted positions ql, ql+16, ...
@@ -804,6 +945,7 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
                                                     const unsigned *__restrict__ perm, int m, int ms,
                                                     const float2 *__restrict__ coarse, int splits,
                                                     const SplitFrame *__restrict__ frames,
+                                                    const NnFrame *__restrict__ gframe,
                                                     int *__restrict__ idx, double *__restrict__ d2out,
                                                     unsigned long long *__restrict__ counters,
                                                     const double *__restrict__ tgt_orig,
@@ -889,45 +1031,10 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
         }
     }
 
-    // phase 3: certificate, split by split (tau depends on the split's frame)
-    const double sq = sqrt(bd);
+    // phase 3: certificate (resolve_certify)
     unsigned extra_slots = 0, extra_splits = 0;
-    for (int e0 = 0; e0 < nact; e0 += 4) {
-        const int e = e0 + quarter;
-        int s = 0;
-        bool whole = false, slot = false;
-        float2 v = make_float2(kBig, kBig);
-        if (e < nact && valid) {
-            s = slist ? slist[e] : e;
-            v = coarse[(size_t)s * n + ic];
-            const float tauf = split_tau(px, py, pz, frames[s], bd, sq);
-            whole = v.y <= tauf;                       // a second column is inside the bound
-            slot = !whole && s != bs && v.x <= tauf;
-        }
-        unsigned long long pend = __ballot(whole || slot);
-        while (pend) {                                 // rare; wave-uniform loop
-            const int L = __ffsll((long long)pend) - 1;
-            pend &= pend - 1;
-            const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
-            const int w = __shfl((int)whole, L, 64);
-            const int c = __shfl((int)(__float_as_uint(v.x) & 31u), L, 64);
-            const int sL = __shfl(s, L, 64);
-            double d = 1.7976931348623157e308;
-            int j = 0x7fffffff;
-            if (w) scan_range(sorted, perm, m, ms, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
-            else scan_range(sorted, perm, m, ms, sL * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
-            if (ql == (L & 15)) { // every replica of that query takes the result
-                if (d < bd || (d == bd && j < bj)) {
-                    bd = d;
-                    bj = j;
-                }
-            }
-            if (lane == L) {
-                if (w) ++extra_splits;
-                else ++extra_slots;
-            }
-        }
-    }
+    resolve_certify<4>(lane, quarter, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
+                       bd, bj, extra_slots, extra_splits);
     if (valid && quarter == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
         if (d2out) d2out[i] = bd;
@@ -1011,6 +1118,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
                                                            const unsigned *__restrict__ perm, int m, int ms,
                                                            const float2 *__restrict__ coarse, int splits,
                                                            const SplitFrame *__restrict__ frames,
+                                                           const NnFrame *__restrict__ gframe,
                                                            int *__restrict__ idx, double *__restrict__ d2out,
                                                            unsigned long long *__restrict__ counters,
                                                            const double *__restrict__ tgt_orig,
@@ -1081,46 +1189,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
         }
     }
 
-    // phase 3: certificate, split by split (tau depends on the split's frame)
-    const double sq = sqrt(bd);
+    // phase 3: certificate (resolve_certify)
     unsigned extra_slots = 0, extra_splits = 0;
-    int nact_max = nact; // wave-uniform already (one block per wave)
-    for (int e0 = 0; e0 < nact_max; e0 += 16) {
-        const int e = e0 + ql;
-        int s = 0;
-        bool whole = false, slot = false;
-        float2 v = make_float2(kBig, kBig);
-        if (e < nact && valid) {
-            s = slist ? slist[e] : e;
-            v = coarse[(size_t)s * n + ic];
-            const float tauf = split_tau(px, py, pz, frames[s], bd, sq);
-            whole = v.y <= tauf;                       // a second column is inside the bound
-            slot = !whole && s != bs && v.x <= tauf;
-        }
-        unsigned long long pend = __ballot(whole || slot);
-        while (pend) {                                 // rare; wave-uniform loop
-            const int L = __ffsll((long long)pend) - 1;
-            pend &= pend - 1;
-            const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
-            const int w = __shfl((int)whole, L, 64);
-            const int c = __shfl((int)(__float_as_uint(v.x) & 31u), L, 64);
-            const int sL = __shfl(s, L, 64);
-            double d = 1.7976931348623157e308;
-            int j = 0x7fffffff;
-            if (w) scan_range(sorted, perm, m, ms, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
-            else scan_range(sorted, perm, m, ms, sL * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
-            if (quarter == (L >> 4)) { // every lane of that query's quarter takes the result
-                if (d < bd || (d == bd && j < bj)) {
-                    bd = d;
-                    bj = j;
-                }
-            }
-            if (lane == L) {
-                if (w) ++extra_splits;
-                else ++extra_slots;
-            }
-        }
-    }
+    resolve_certify<16>(lane, ql, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
+                        bd, bj, extra_slots, extra_splits);
     if (valid && ql == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
         if (d2out) d2out[i] = bd;
@@ -1526,11 +1598,14 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const double *__restrict__
 // global best are popped by k rounds of a workgroup-wide argmin over the list heads.
 // With `perm` the listed rows are sorted positions (pruned engine): row r is point perm[r] and its
 // list is stored at r.
+// `qry` (may be null: the rows are rows of `pts`) holds the rows' coordinates when the queries are
+// not the targets themselves (icpmi_k_nearest).
 __global__ __launch_bounds__(256) void k_knn_exact_rows(const double *__restrict__ pts, int m, int k,
                                                         const int *__restrict__ list,
                                                         const int *__restrict__ list_count,
                                                         int *__restrict__ knn_idx,
-                                                        const unsigned *__restrict__ perm)
+                                                        const unsigned *__restrict__ perm,
+                                                        const double *__restrict__ qry)
 {
     extern __shared__ double knn_smem[];
     constexpr int BLOCK = 256;
@@ -1543,7 +1618,8 @@ __global__ __launch_bounds__(256) void k_knn_exact_rows(const double *__restrict
     for (int lr = blockIdx.x; lr < nrows; lr += gridDim.x) { // block-uniform
         const int i = list[lr];
         const size_t ip = perm ? perm[i] : (unsigned)i;
-        const double px = pts[3 * ip], py = pts[3 * ip + 1], pz = pts[3 * ip + 2];
+        const double *qp = qry ? qry : pts;
+        const double px = qp[3 * ip], py = qp[3 * ip + 1], pz = qp[3 * ip + 2];
         int cnt = 0;
         double thr = __builtin_inf();
         for (int j = tid; j < m; j += BLOCK) {
@@ -1608,18 +1684,20 @@ __global__ __launch_bounds__(BLOCK) void k_knn_exact_list(const double *__restri
                                                           int row0, int row1,
                                                           const int *__restrict__ list,
                                                           const int *__restrict__ list_count,
-                                                          int *__restrict__ knn_idx)
+                                                          int *__restrict__ knn_idx,
+                                                          const double *__restrict__ qry)
 {
     extern __shared__ double knn_smem[];
     double *ld = knn_smem;
     int *li = reinterpret_cast<int *>(knn_smem + (size_t)k * BLOCK);
     const int tid = threadIdx.x;
+    const double *qp = qry ? qry : pts;
     const int nrows = list ? *list_count : row1 - row0;
     for (int base = blockIdx.x * BLOCK; base < nrows; base += gridDim.x * BLOCK) { // block-uniform
         const int lr = base + tid;
         const bool active = lr < nrows;
         const int i = active ? (list ? list[lr] : row0 + lr) : (list ? list[0] : row0);
-        const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+        const double px = qp[3 * i], py = qp[3 * i + 1], pz = qp[3 * i + 2];
         int cnt = active ? 0 : k;
         double thr = active ? __builtin_inf() : -1.0;
 #pragma unroll 4
@@ -1643,6 +1721,18 @@ __global__ __launch_bounds__(BLOCK) void k_knn_exact_list(const double *__restri
         if (active)
             for (int a = 0; a < cnt; ++a) knn_idx[(size_t)i * k + a] = li[a * BLOCK + tid];
     }
+}
+
+// squared distances of finished neighbour lists (entries < 0: no neighbour, distance left untouched)
+__global__ __launch_bounds__(256) void k_knn_distances(const double *__restrict__ qry, int nq, const double *__restrict__ tgt,
+                                                       int m, int k, const int *__restrict__ knn_idx,
+                                                       double *__restrict__ d2)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)nq * k) return;
+    const int i = (int)(e / k), j = knn_idx[e];
+    if ((unsigned)j < (unsigned)m)
+        d2[e] = sqdist(tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2], qry[3 * i], qry[3 * i + 1], qry[3 * i + 2]);
 }
 
 // PCA normal from a closest-first neighbour list (icp.hpp:34-63), one row per thread

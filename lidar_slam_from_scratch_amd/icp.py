@@ -9,6 +9,7 @@ Same names, argument meaning and result fields as the reference's C++ API
     icp_point_to_plane    icp.hpp:157-258
     estimate_normals      icp.hpp:23-67
     solve_point_to_plane  icp.hpp:89-144
+    KDTree                kdtree.hpp:18-186 (nearest, nearest_batch, k_nearest)
     NearestNeighborSearch kdtree.hpp:193-221
     ICP(...).align()      the facade BASELINE.json's north_star names
 
@@ -164,6 +165,36 @@ def solve_point_to_plane(source, target, normals, ctx=None):
     return Transformation((ctx or default_context()).solve_point_to_plane(source, target, normals))
 
 
+class KDTree:
+    """kdtree.hpp:18-186 -- the name and the queries of the reference's tree; the search behind
+    them is exhaustive on the GPU (same exact answers, no tree is built)."""
+
+    def __init__(self, points, ctx=None):
+        self._points = np.ascontiguousarray(_pts(points), dtype=np.float64)
+        self._ctx = ctx or default_context()
+
+    def size(self):
+        return self._points.shape[0]
+
+    def nearest(self, query):
+        """kdtree.hpp:28-38 -> (index, squared distance)"""
+        idx, d2 = self._ctx.nearest_batch(self._points, np.asarray(query, dtype=np.float64).reshape(1, 3))
+        return int(idx[0]), float(d2[0])
+
+    def nearest_batch(self, queries):
+        """kdtree.hpp:43-59 -> (indices, distances_sq)"""
+        return self._ctx.nearest_batch(self._points, _pts(queries))
+
+    def k_nearest(self, query, k):
+        """kdtree.hpp:65-78 -> indices of the k nearest points, closest first (at most size() of them)"""
+        idx, _ = self._ctx.k_nearest(self._points, np.asarray(query, dtype=np.float64).reshape(1, 3), k, want_dist=False)
+        return [int(j) for j in idx[0] if j >= 0]
+
+    def k_nearest_batch(self, queries, k):
+        """k_nearest for every row of `queries` -> (indices n x k, distances_sq n x k); -1 / inf where a list ends"""
+        return self._ctx.k_nearest(self._points, _pts(queries), k)
+
+
 class NearestNeighborSearch:
     """kdtree.hpp:193-221"""
 
@@ -179,6 +210,10 @@ class NearestNeighborSearch:
         """kdtree.hpp:198-214 -> (matched_target, distances)"""
         idx, d2 = self.nearest_batch(source)
         return self._target[idx], np.sqrt(d2)
+
+    def tree(self):
+        """kdtree.hpp:216"""
+        return KDTree(self._target, self._ctx)
 
 
 class ICP:

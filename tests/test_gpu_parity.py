@@ -546,6 +546,44 @@ def test_nonfinite_input_is_memory_safe(gpu_ctx):
     assert np.isfinite(res.final_error)                 # the context still works
 
 
+@pytest.mark.parametrize("m,k", [(700, 5), (700, 20), (12000, 1), (12000, 20), (12000, 32), (12000, 40)])
+def test_k_nearest_matches_oracle(gpu_ctx, oracle, m, k):
+    """icpmi_k_nearest = KDTree::k_nearest (kdtree.hpp:65-78) for a batch: closest first, the query
+    point itself included when it is a target (distance 0).  Against the oracle's kd-tree k-NN
+    and its brute-force form, for queries that are targets and queries that are not."""
+    _, tgt, _ = synth.c3_uniform(m, seed=71 + m, perm_seed=72)
+    rng = np.random.default_rng(5)
+    qry = np.vstack([tgt[rng.choice(m, 40, replace=False)],                       # targets themselves
+                     tgt[rng.choice(m, 40, replace=False)] + rng.normal(0, 0.3, (40, 3)),
+                     rng.uniform(-60, 60, (20, 3))])                              # partly outside the cloud
+    idx, d2 = gpu_ctx.k_nearest(tgt, qry, k)
+    assert idx.shape == (100, k) and d2.shape == (100, k)
+    tree = oracle.KDTree(tgt)
+    for i in range(qry.shape[0]):
+        want = oracle.k_nearest_brute(tgt, qry[i], k)
+        assert list(idx[i]) == list(want), i
+        assert list(tree.k_nearest(qry[i], k)) == list(want), i
+        assert (d2[i] == ((tgt[want] - qry[i]) ** 2).sum(axis=1)).all() or np.allclose(d2[i], ((tgt[want] - qry[i]) ** 2).sum(axis=1), rtol=1e-15, atol=0)
+        assert (np.diff(d2[i]) >= 0).all()
+    assert (idx[:40, 0] == np.array([np.flatnonzero((tgt == q).all(axis=1))[0] for q in qry[:40]])).all()
+
+
+def test_k_nearest_edge_cases(gpu_ctx):
+    from lidar_slam_from_scratch_amd import icp
+    tgt = np.array([[0.0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3], [5, 5, 5]])
+    idx, d2 = gpu_ctx.k_nearest(tgt, np.array([[0.1, 0, 0], [np.nan, 0, 0]]), 8)
+    assert list(idx[0]) == [0, 1, 2, 3, 4, -1, -1, -1]              # k > n_tgt: the list ends, kdtree.hpp:66-67
+    assert np.isinf(d2[0, 5:]).all() and np.allclose(d2[0, :2], [0.01, 0.81])
+    assert (idx[1] == -1).all()                                      # NaN query: nothing compares less
+    with pytest.raises(capi.IcpError):
+        gpu_ctx.k_nearest(tgt, tgt, 0)
+    with pytest.raises(capi.IcpError):
+        gpu_ctx.k_nearest(np.zeros((0, 3)), tgt, 3)
+    tree = icp.KDTree(tgt, ctx=gpu_ctx)
+    assert tree.k_nearest([0.1, 0, 0], 3) == [0, 1, 2] and tree.nearest([4, 4, 4])[0] == 4
+    assert tree.k_nearest([0.1, 0, 0], 9) == [0, 1, 2, 3, 4]
+
+
 def test_nonfinite_targets_are_never_neighbours(gpu_ctx, oracle):
     """A target with an Inf or NaN coordinate has no finite distance to anything, so no
     `dist_sq < best` (kdtree.hpp:125) ever selects it: every engine must return the nearest of
