@@ -12,8 +12,9 @@
 // second rounded to nearest: relative error <= 2^-16) and the contraction carries the 4
 // cross products per axis, plus |Q|^2 as three exact pieces against a constant 1:
 //     |P-Q|^2 ~ |P|^2 + sum_axis sum_{i,j<2} P_i * (-2 Q_j) + 1 * |Q|^2
-// K = 12 + 3 = 15 <= 16: ONE v_mfma_f32_32x32x16_bf16 per 32 queries x 32 targets, every
-// product exact in fp32, fp32 accumulation, two v_min3_f32 per 256 pairs.
+// and the leading bf16 piece of |P|^2 against a constant 1 (what is left of |P|^2, < 2^-7 |P|^2,
+// is added in the epilogue): K = 12 + 3 + 1 = 16: ONE v_mfma_f32_32x32x16_bf16 per 32 queries x
+// 32 targets, every product exact in fp32, fp32 accumulation, two v_min3_f32 per 256 pairs.
 //
 // Geometry.  Targets are Morton-sorted once per call (the target does not move during the
 // ICP loop) and cut into splits of 2048; every split has its own centre c_s and radius
@@ -37,14 +38,16 @@
 //     then two bf16 pieces); BOTH norms are those of the represented points, so the
 //     contraction is |P~ - Q~|^2 of two slightly moved points and, with
 //     eps = (2^-16 + 2^-24) a (1 + 1e-6):   | |P~-Q~|^2 - |p-q|^2 | <= eps (2 sqrt(d) + eps)
-//   arithmetic: the 15 products are exact; their fp32 accumulation inside the MFMA is not
-//     specified, so every one of the <= 17 additions is charged a full truncation
-//     (2u x the largest magnitude, <= a^2): 34 u a^2; plus fl32(|Q|^2), fl32(|P|^2) formed
-//     with 5 roundings, and the final add: 41 u a^2.
+//   arithmetic: the 16 products are exact; their fp32 accumulation inside the MFMA is not
+//     specified, so every one of the <= 18 additions is charged a full truncation
+//     (2u x the largest magnitude, <= a^2): 36 u a^2; plus fl32(|Q|^2), fl32(|P|^2) formed
+//     with 5 roundings, and the final add: 43 u a^2.
 //   column tag (1-NN epilogue): the column number replaces the 5 low mantissa bits of the
-//     contraction BEFORE |P|^2 is added (|contraction| <= |Q|^2 + 2|P||Q| <= a^2: 32 u a^2), the sum
-//     is truncated and tagged again (< 2^-19 relative on the stored minimum: the 4e-6 inflation).
-//   88 u a^2 is used (73 + margin).
+//     contraction BEFORE the rest of |P|^2 is added; the contraction already holds the leading
+//     piece of |P|^2, so it is within 2^-7 a^2 of the squared distance d: the tag moves it by
+//     < 2^-19 (d + 2^-7 a^2) = 2^-19 d + u a^2 / 4; the sum is truncated and tagged again, another
+//     2^-19 d (both relative parts are the 4e-6 inflation of tau).
+//   52 u a^2 is used.
 //
 // Engine 3 (ICPMI_SEARCH_MFMA_PRUNED, opt-in) runs the same coarse unit and the same resolve on
 // fewer (query block, split) units: k_transform_bounds / k_knn_block_bounds bound, per block of
@@ -75,7 +78,10 @@ constexpr int kCoarseWaves = 8;                   // waves per workgroup
 constexpr int kCoarseThreads = 64 * kCoarseWaves;
 constexpr int kCoarseQueries = kTile * kCoarseQT * kCoarseWaves; // queries per workgroup
 constexpr float kBig = 3.0e38f;
-constexpr double kArithBound = 88.0;              // x u a^2, see above
+#ifndef ICPMI_ARITH_BOUND
+#define ICPMI_ARITH_BOUND 52.0
+#endif
+constexpr double kArithBound = ICPMI_ARITH_BOUND; // x u a^2, see above (build-time override: A/B timing only)
 constexpr double kReprEps = 1.52587890625e-05 + 5.9604644775390625e-08; // 2^-16 + 2^-24
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -285,7 +291,7 @@ __device__ __forceinline__ void split2(float x, unsigned &h, unsigned &m)
 
 // K-slot k of the contraction (K = 16):
 //   k = 4*axis + 2*i + j (k < 12): A = P_axis piece i, B = -2 * Q_axis piece j
-//   k = 12..14: A = 1, B = piece (k-12) of fl32(|Q|^2);  k = 15: both 0
+//   k = 12..14: A = 1, B = piece (k-12) of fl32(|Q|^2);  k = 15: A = leading bf16 piece of |P|^2, B = 1
 
 // ---- targets -> bf16 B operands: Bpack[(s*64 + t)*64 + lane] = 8 bf16 (k = 8*(lane>>5)+e) ----------
 // tile t, column c = lane&31 of split s is sorted position s*2048 + c*64 + t
@@ -323,6 +329,8 @@ __global__ __launch_bounds__(256) void k_pack_targets(const double *__restrict__
             v = __float_as_uint(-2.0f * __uint_as_float(b << 16)) >> 16; // exact
         } else if (k < 15) {
             v = np[k - 12];
+        } else {
+            v = 0x3f80u; // 1.0: carries the leading piece of |P|^2 (also for padding: kBig swallows it)
         }
         w[e] = v & 0xFFFFu;
     }
@@ -401,10 +409,14 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
                 const float tz = __uint_as_float(zh << 16) + __uint_as_float(zm << 16);
                 pn[gq] = (tx * tx + ty * ty) + tz * tz;
             }
+            // leading piece of |P|^2 (truncated: exact difference) goes through the matrix core,
+            // the epilogue adds the rest
+            const unsigned pnh = __float_as_uint(pn[gq]) >> 16;
+            pn[gq] -= __uint_as_float(pnh << 16);
             const unsigned one = 0x3f80u;
-            // slots: x: h h m m, y: h h m m | z: h h m m, 1 1 1 0
+            // slots: x: h h m m, y: h h m m | z: h h m m, 1 1 1 |P|^2
             rows[lane * 2 + 0] = make_uint4(xh | (xh << 16), xm | (xm << 16), yh | (yh << 16), ym | (ym << 16));
-            rows[lane * 2 + 1] = make_uint4(zh | (zh << 16), zm | (zm << 16), one | (one << 16), one);
+            rows[lane * 2 + 1] = make_uint4(zh | (zh << 16), zm | (zm << 16), one | (one << 16), one | (pnh << 16));
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -876,7 +888,11 @@ __device__ __forceinline__ void resolve_certify(const int lane, const int sub, c
                                                 unsigned &extra_slots, unsigned &extra_splits)
 {
     const double sq = sqrt(bd);
+#ifdef ICPMI_NO_FIRST_FILTER /* A/B timing only */
+    const float tmax = 3.4028235e38f;
+#else
     const float tmax = all_splits_tau(px, py, pz, *gframe, bd, sq);
+#endif
     // a query with a NaN or infinite coordinate has no neighbour whatever is scanned (kdtree.hpp:125
     // never holds): it takes no part
     const bool look = valid && finite3(px, py, pz);
@@ -939,8 +955,22 @@ __device__ __forceinline__ void resolve_certify(const int lane, const int sub, c
 // of the slot: three coalesced streams), so 4 slots are in flight per wave and ~6 waves per
 // SIMD hide the latency.
 constexpr int kResolveQ = 16;
+// Waves per SIMD the register allocation must allow (A/B knob).  The kernel waits on memory three
+// quarters of the time (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.77) and, at 64 queries per workgroup, C3
+// has 1,563 workgroups: at 5 per CU (82 VGPRs) 283 of them form a second round.  Forcing 6 / 7
+// waves per SIMD (80 / 72 VGPRs, 11 spilled at 7) measured 52 / 54 us against 48 us at 5: kept at 5.
+#ifndef ICPMI_RESOLVE_OCC
+#define ICPMI_RESOLVE_OCC 5
+#endif
+#ifndef ICPMI_RESOLVE_UNROLL
+#define ICPMI_RESOLVE_UNROLL 4
+#endif
+#ifndef ICPMI_RESOLVE_RUNROLL
+#define ICPMI_RESOLVE_RUNROLL 4
+#endif
 
-__global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ qry, int n,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOLVE_OCC, 8))) void k_nn_resolve(
+    const double *__restrict__ qry, int n,
                                                     const double *__restrict__ sorted,
                                                     const unsigned *__restrict__ perm, int m, int ms,
                                                     const float2 *__restrict__ coarse, int splits,
@@ -994,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
     // phase 2: exact evaluation of the winning slots, one query per quarter-wave and round
     double bd = 1.7976931348623157e308;
     int bj = 0x7fffffff;
-#pragma unroll
+#pragma unroll ICPMI_RESOLVE_RUNROLL
     for (int r = 0; r < 4; ++r) {
         const int src = quarter * 4 + r; // the query this quarter scans now (a lane of quarter 0)
         const double qx = __shfl(px, src, 64), qy = __shfl(py, src, 64), qz = __shfl(pz, src, 64);
@@ -1002,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
         const int j0 = s * kSplitTargets + c * kSlotTargets + ql; // lane takes ql, ql+16, ...: coalesced
         double d = 1.7976931348623157e308;
         int j = 0x7fffffff;
-#pragma unroll
+#pragma unroll ICPMI_RESOLVE_UNROLL
         for (int o = 0; o < kSlotTargets / 16; ++o) {
             const int jj = j0 + 16 * o;
             const int jc = jj < m ? jj : m - 1;
@@ -1054,38 +1084,34 @@ __global__ __launch_bounds__(256) void k_nn_resolve(const double *__restrict__ q
     // owners of a wave form their J row and b, the 28 sums go wave -> LDS -> one partial row
     // per workgroup, summed later in a fixed order by k_finish_step
     if (partials) {
-        double acc[28];
-#pragma unroll
-        for (int e = 0; e < 28; ++e) acc[e] = 0.0;
-        if (valid && quarter == 0) {
-            const int j = (unsigned)bj < (unsigned)m ? bj : 0;
-            const double q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
-            const double n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
-            double J[6];
-            J[0] = py * n2 - pz * n1; // p x n, icp.hpp:105
-            J[1] = pz * n0 - px * n2;
-            J[2] = px * n1 - py * n0;
-            J[3] = n0;
-            J[4] = n1;
-            J[5] = n2;
-            const double e0 = q0 - px, e1 = q1 - py, e2 = q2 - pz;
-            const double b = (e0 * n0 + e1 * n1) + e2 * n2; // icp.hpp:116
-            int o = 0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c = r; c < 6; ++c) acc[o++] = J[r] * J[c];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) acc[21 + r] = J[r] * b;
-            acc[27] = b * b;
-        }
         // 16 rows of 28 terms per wave -> LDS (row stride 29: conflict-free), then lane l sums
         // column l & 31 over the 8 rows of half l >> 5 and the halves meet with one exchange
         __shared__ double jrow[4][16][29];
         __shared__ double red[4][28];
-        if (quarter == 0) {
+        if (quarter == 0) { // each term goes to LDS as it is formed (28 live doubles would cost 2 waves per SIMD)
+            double J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, b = 0.0;
+            if (valid) {
+                const int j = (unsigned)bj < (unsigned)m ? bj : 0;
+                const double q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
+                const double n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
+                J[0] = py * n2 - pz * n1; // p x n, icp.hpp:105
+                J[1] = pz * n0 - px * n2;
+                J[2] = px * n1 - py * n0;
+                J[3] = n0;
+                J[4] = n1;
+                J[5] = n2;
+                const double e0 = q0 - px, e1 = q1 - py, e2 = q2 - pz;
+                b = (e0 * n0 + e1 * n1) + e2 * n2; // icp.hpp:116
+            }
+            double *row = jrow[wave][ql];
+            int o = 0;
 #pragma unroll
-            for (int e = 0; e < 28; ++e) jrow[wave][ql][e] = acc[e];
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) row[o++] = J[r] * J[c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) row[21 + r] = J[r] * b;
+            row[27] = b * b;
         }
         __builtin_amdgcn_wave_barrier();
         {

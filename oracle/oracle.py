@@ -15,6 +15,11 @@ _LIB = None
 
 
 def build(force=False):
+    # ORACLE_SANITIZE=1: the AddressSanitizer + UBSan build (tests/test_oracle_residual_risk.py runs
+    # the known-answer tests through it in a child process that preloads libasan)
+    if os.environ.get("ORACLE_SANITIZE") == "1":
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libicp_oracle_asan.so"])
+        return os.path.join(_HERE, "libicp_oracle_asan.so")
     so = os.path.join(_HERE, "libicp_oracle.so")
     src = os.path.join(_HERE, "icp_oracle.c")
     hdr = os.path.join(_HERE, "icp_oracle.h")

@@ -584,6 +584,31 @@ def test_k_nearest_edge_cases(gpu_ctx):
     assert tree.k_nearest([0.1, 0, 0], 9) == [0, 1, 2, 3, 4]
 
 
+def test_ring_neighbourhood_normals_bit_exact(gpu_ctx, oracle):
+    """Far-range LiDAR rings: every 20-neighbourhood is a nearly collinear arc, the covariance
+    has two tiny, nearly equal eigenvalues -- where a Jacobi sweep and its GPU twin would part
+    first if their operation orders differed.  Normals and neighbour lists must still be the
+    oracle's bit for bit (the oracle itself is checked against numpy.linalg.eigh on this data in
+    tests/test_oracle_residual_risk.py)."""
+    from test_oracle_residual_risk import ring_cloud
+    pts = ring_cloud(rings=8, per_ring=1800, seed=3)
+    assert pts.shape[0] >= 8192                       # the MFMA engines take their k-NN path
+    got = gpu_ctx.estimate_normals(pts, 20)
+    want = oracle.estimate_normals(pts, None, 20, nthreads=8)
+    assert (got == want).all()
+    idx, _ = gpu_ctx.k_nearest(pts, pts[::97], 20)
+    tree = oracle.KDTree(pts)
+    for r, i in enumerate(range(0, pts.shape[0], 97)):
+        assert list(idx[r]) == list(tree.k_nearest(pts[i], 20))
+    # a registration on this geometry: same iteration count and history as the oracle
+    T = synth.make_transform((0.0, 0.0, 0.01), (0.2, -0.1, 0.0))
+    src = (pts[::2] - T[:3, 3]) @ T[:3, :3]
+    res, hist = gpu_ctx.align(src, pts, capi.Context.make_config(15, 1e-6, 1e-9))
+    ref = oracle.icp_point_to_plane(src, pts, 15, 1e-6, 1e-9, nthreads=8)
+    assert res.num_iterations == ref.num_iterations and bool(res.converged) == ref.converged
+    np.testing.assert_allclose(hist, ref.error_history, rtol=0, atol=1e-9)
+
+
 def test_nonfinite_targets_are_never_neighbours(gpu_ctx, oracle):
     """A target with an Inf or NaN coordinate has no finite distance to anything, so no
     `dist_sq < best` (kdtree.hpp:125) ever selects it: every engine must return the nearest of
