@@ -172,6 +172,60 @@ int icpmi_voxel_downsample_device(icpmi_ctx *ctx, const double *d_points_xyz, in
  * reference throws std::runtime_error). */
 int icpmi_load_cloud(const char *path, double *out_xyz, int64_t cap, int64_t *n_out);
 
+/* Replaces discover_frames + extract_timestamp (slam_viz/src/core/file_utils.cpp:203-247): the
+ * entries of data_dir whose extension is ".ply" or ".bin" and whose name holds a run of digits in
+ * front of that extension, sorted by that number (equal numbers by path).  Two-call pattern: with
+ * stamps == paths == NULL only *n_frames and *paths_bytes are set; then stamps[n_frames] and
+ * paths (NUL-terminated strings, one after the other, paths_bytes in all) are filled.  A
+ * directory that cannot be opened returns ICPMI_ERR_ARG (the reference throws).  Host-side. */
+int icpmi_discover_frames(const char *data_dir, int64_t *stamps, int64_t frames_cap, char *paths,
+                          int64_t paths_cap, int64_t *n_frames, int64_t *paths_bytes);
+
+/* The device form of load_bin (file_utils.cpp:115-141): host float32 records (x, y, z leading,
+ * stride_floats apart: 4 for KITTI) are copied to the device as they are and widened to the
+ * N x 3 fp64 layout there (static_cast<double> is exact either side): 16 instead of 24 bytes per
+ * point cross the host link.  d_out_xyz: device pointer, n rows. */
+int icpmi_upload_points_f32(icpmi_ctx *ctx, const float *records, int64_t n, int32_t stride_floats,
+                            double *d_out_xyz);
+/* icpmi_load_cloud into device memory: ".bin" through icpmi_upload_points_f32, PLY parsed on the
+ * host (header rules, ASCII numbers) and uploaded as fp64.  Two-call pattern like icpmi_load_cloud
+ * (d_out_xyz == NULL: only *n_out). */
+int icpmi_load_cloud_device(icpmi_ctx *ctx, const char *path, double *d_out_xyz, int64_t cap,
+                            int64_t *n_out);
+
+/* estimate_normals (icp.hpp:23-67) for rows [row0, row1) of the cloud only, against the whole
+ * cloud: what one rank of a job that shards the normal estimation itself computes.  normals_xyz
+ * receives row1 - row0 rows.  Host pointers. */
+int icpmi_estimate_normals_rows(icpmi_ctx *ctx, const double *points_xyz, int64_t n, int32_t k,
+                                int64_t row0, int64_t row1, double *normals_xyz);
+
+/* One step of frame-to-frame odometry with the clouds resident in HBM: the registration part of
+ * SlamNode::process_frame (slam_viz/src/ros/slam_node.cpp:122-152).
+ *     curr = voxel_downsample(raw, voxel_size)                       :122
+ *     first frame: keep it, nothing to register                      :69-72   -> ICPMI_STREAM_FIRST_FRAME
+ *     curr.rows() < min_points: keep it, caller repeats its last pose :125-130 -> ICPMI_STREAM_TOO_FEW_POINTS
+ *     result = icp_point_to_plane(source = curr, target = prev, cfg) :132-138 -> ICPMI_STREAM_REGISTERED
+ *     prev = curr                                                    :128,152
+ * The context keeps the previous filtered scan in device memory (the target of frame t+1 is the
+ * source of frame t; buffers are swapped, nothing is copied or uploaded twice), builds the
+ * target's search structure and normals from that resident copy, and the caller applies the
+ * reference's gate (!converged || final_error > 1.0 -> identity, :139-140) and pose update.
+ * d_raw_xyz: device pointer to the raw scan (e.g. from icpmi_load_cloud_device).  In the first
+ * two cases *result is the identity with converged = 0 and no history. */
+#define ICPMI_STREAM_REGISTERED 0
+#define ICPMI_STREAM_FIRST_FRAME 1
+#define ICPMI_STREAM_TOO_FEW_POINTS 2
+typedef struct {
+    int32_t status;      /* ICPMI_STREAM_* */
+    int32_t reserved;
+    int64_t n_filtered;  /* rows of the filtered current scan (now the resident "previous" one) */
+    int64_t n_target;    /* rows of the scan it was registered against */
+} icpmi_stream_info;
+int icpmi_stream_push(icpmi_ctx *ctx, const double *d_raw_xyz, int64_t n_raw, double voxel_size,
+                      int64_t min_points, const icpmi_config *cfg, icpmi_result *result,
+                      double *error_history, int32_t history_cap, icpmi_stream_info *info);
+int icpmi_stream_reset(icpmi_ctx *ctx);   /* forget the resident frame (a new sequence starts) */
+
 /* Replaces ScanContext::compute (core/scan_context.hpp:44-82): 20 rings x 60 sectors max-height
  * descriptor, row-major desc_out[ring * 60 + sector], empty bins 0. */
 #define ICPMI_SC_RINGS 20

@@ -22,7 +22,9 @@ EXPORTS = [
     "icpmi_nearest_batch", "icpmi_k_nearest", "icpmi_estimate_normals", "icpmi_solve_point_to_plane",
     "icpmi_transform_points", "icpmi_comm_unique_id", "icpmi_comm_init", "icpmi_comm_finalize",
     "icpmi_comm_init_callbacks", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
-    "icpmi_scan_context", "icpmi_scan_context_distances", "icpmi_load_cloud",
+    "icpmi_scan_context", "icpmi_scan_context_distances", "icpmi_load_cloud", "icpmi_load_cloud_device",
+    "icpmi_upload_points_f32", "icpmi_discover_frames", "icpmi_estimate_normals_rows",
+    "icpmi_stream_push", "icpmi_stream_reset",
     "icpmi_reset_profile", "icpmi_get_profile",
 ]
 
@@ -56,6 +58,12 @@ class Profile(C.Structure):
                 ("nn_fallback_queries", C.c_int64), ("knn_fallback_rows", C.c_int64),
                 ("nn_coarse_blocks", C.c_int64), ("nn_pruned_blocks", C.c_int64)]
 
+
+class StreamInfo(C.Structure):
+    _fields_ = [("status", C.c_int32), ("reserved", C.c_int32), ("n_filtered", C.c_int64), ("n_target", C.c_int64)]
+
+
+STREAM_REGISTERED, STREAM_FIRST_FRAME, STREAM_TOO_FEW_POINTS = 0, 1, 2
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
@@ -145,6 +153,13 @@ def load_library(path=None):
     L.icpmi_voxel_downsample.argtypes = [vp, dp, C.c_int64, C.c_double, dp, C.c_int64, i64p]
     L.icpmi_voxel_downsample_device.argtypes = [vp, vp, C.c_int64, C.c_double, vp, C.c_int64, i64p]
     L.icpmi_load_cloud.argtypes = [C.c_char_p, dp, C.c_int64, i64p]
+    L.icpmi_load_cloud_device.argtypes = [vp, C.c_char_p, vp, C.c_int64, i64p]
+    L.icpmi_upload_points_f32.argtypes = [vp, C.POINTER(C.c_float), C.c_int64, C.c_int32, vp]
+    L.icpmi_discover_frames.argtypes = [C.c_char_p, i64p, C.c_int64, C.c_char_p, C.c_int64, i64p, i64p]
+    L.icpmi_estimate_normals_rows.argtypes = [vp, dp, C.c_int64, C.c_int32, C.c_int64, C.c_int64, dp]
+    L.icpmi_stream_push.argtypes = [vp, vp, C.c_int64, C.c_double, C.c_int64, C.POINTER(Config), C.POINTER(Result), dp,
+                                    C.c_int32, C.POINTER(StreamInfo)]
+    L.icpmi_stream_reset.argtypes = [vp]
     L.icpmi_scan_context.argtypes = [vp, dp, C.c_int64, dp]
     L.icpmi_scan_context_distances.argtypes = [vp, dp, dp, C.c_int64, dp]
     L.icpmi_comm_unique_id.argtypes = [vp, vp]
@@ -171,6 +186,24 @@ def load_cloud(path):
     if rc != OK:
         raise IcpError(rc, L.icpmi_last_error(None).decode())
     return out
+
+
+def discover_frames(data_dir):
+    """discover_frames (file_utils.cpp:217-247) through the library -> [(number, path), ...] sorted by number."""
+    L = load_library()
+    n, nbytes = C.c_int64(0), C.c_int64(0)
+    rc = L.icpmi_discover_frames(os.fsencode(data_dir), None, 0, None, 0, C.byref(n), C.byref(nbytes))
+    if rc != OK:
+        raise IcpError(rc, L.icpmi_last_error(None).decode())
+    if n.value == 0:
+        return []
+    stamps = (C.c_int64 * n.value)()
+    buf = C.create_string_buffer(nbytes.value)
+    rc = L.icpmi_discover_frames(os.fsencode(data_dir), stamps, n.value, buf, nbytes.value, C.byref(n), C.byref(nbytes))
+    if rc != OK:
+        raise IcpError(rc, L.icpmi_last_error(None).decode())
+    paths = buf.raw[:nbytes.value].split(b"\0")[:n.value]
+    return [(int(stamps[i]), os.fsdecode(paths[i])) for i in range(n.value)]
 
 
 def _f64(a, cols=3):
@@ -292,6 +325,42 @@ class Context:
         self._check(self._lib.icpmi_voxel_downsample_device(self._h, C.c_void_p(src_ptr), n, float(voxel_size),
                                                             C.c_void_p(out_ptr), out_cap, C.byref(n_out)))
         return n_out.value
+
+    def estimate_normals_rows(self, points, k, row0, row1):
+        """icp.hpp:23-67 for rows [row0, row1) only (against the whole cloud)"""
+        pts = _f64(points)
+        out = np.empty((row1 - row0, 3))
+        self._check(self._lib.icpmi_estimate_normals_rows(self._h, _dp(pts), pts.shape[0], k, row0, row1, _dp(out)))
+        return out
+
+    def upload_points_f32(self, records, out_ptr):
+        """records: n x stride float32 (x, y, z leading) -> n x 3 fp64 at device address out_ptr"""
+        rec = np.ascontiguousarray(records, dtype=np.float32)
+        self._check(self._lib.icpmi_upload_points_f32(self._h, rec.ctypes.data_as(C.POINTER(C.c_float)), rec.shape[0],
+                                                      rec.shape[1], C.c_void_p(out_ptr)))
+
+    def load_cloud_device_rows(self, path):
+        n = C.c_int64(0)
+        self._check(self._lib.icpmi_load_cloud_device(self._h, os.fsencode(path), None, 0, C.byref(n)))
+        return n.value
+
+    def load_cloud_device(self, path, out_ptr, cap):
+        """load_ply / load_bin (file_utils.cpp:20-141) straight into device memory; returns the row count"""
+        n = C.c_int64(0)
+        self._check(self._lib.icpmi_load_cloud_device(self._h, os.fsencode(path), C.c_void_p(out_ptr), cap, C.byref(n)))
+        return n.value
+
+    def stream_push(self, raw_ptr, n_raw, voxel, min_points, cfg):
+        """slam_node.cpp:122-152 on resident clouds -> (Result, error history, StreamInfo)"""
+        cap = cfg.max_iterations + 1
+        hist = np.zeros(max(cap, 1))
+        res, info = Result(), StreamInfo()
+        self._check(self._lib.icpmi_stream_push(self._h, C.c_void_p(raw_ptr), n_raw, float(voxel), int(min_points),
+                                                C.byref(cfg), C.byref(res), _dp(hist), cap, C.byref(info)))
+        return res, hist[:res.history_len].copy(), info
+
+    def stream_reset(self):
+        self._check(self._lib.icpmi_stream_reset(self._h))
 
     def scan_context(self, cloud):
         """scan_context.hpp:44-82 -> 20 x 60 descriptor"""

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <dirent.h>
 #include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
@@ -116,6 +117,8 @@ struct icpmi_ctx {
     DevBuf cur, nrm, idx, part_d2, part_idx, partials, history, stage_a, stage_b, stage_c, d2out;
     DevBuf knn_idx, slotmin, fb_list;         // k-NN lists, slot minima, rows for the exact fallback
     DevBuf vox_keys, vox_vals, vox_out;             // voxel filter: 64-bit keys (in/out/unique), values + run data, result
+    DevBuf stream_prev, stream_cur, f32_stage;      // odometry stream: previous / current filtered scan; float32 upload staging
+    int64_t stream_prev_n = -1;                     // rows of stream_prev (-1: no frame yet)
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     DevBuf src_sort, blk_lists, work;         // pruned engine: Morton order of the source, per-block split lists, unit list
@@ -964,7 +967,7 @@ void icpmi_destroy(icpmi_ctx *ctx)
                       &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out, &ctx->src_sort, &ctx->blk_lists, &ctx->work,
                       &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin,
                       &ctx->fb_list, &ctx->sort_keys, &ctx->sort_tmp, &ctx->tgt_sorted, &ctx->frames, &ctx->vox_keys,
-                      &ctx->vox_vals, &ctx->vox_out})
+                      &ctx->vox_vals, &ctx->vox_out, &ctx->stream_prev, &ctx->stream_cur, &ctx->f32_stage})
         release(*b);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -1304,6 +1307,204 @@ int icpmi_load_cloud(const char *path, double *out_xyz, int64_t cap, int64_t *n_
             for (int a2 = 0; a2 < 3; ++a2) out_xyz[3 * i + a2] = v[a2];
         }
     }
+    return ICPMI_OK;
+}
+
+// ---- frame files of a sequence directory (file_utils.cpp:203-247) ---------------------------------
+// The reference's std::regex_search(filename, "(\\d+)\\.ply") finds the leftmost run of digits that is
+// followed by the extension: a run followed by anything else can only fail (the greedy \d+ has
+// nothing to give back that "\\." would match), so no regex engine is needed.
+static bool frame_number(const char *name, const char *ext, long long *out)
+{
+    const size_t el = strlen(ext);
+    for (size_t i = 0; name[i];) {
+        if (name[i] < '0' || name[i] > '9') {
+            ++i;
+            continue;
+        }
+        size_t j = i;
+        while (name[j] >= '0' && name[j] <= '9') ++j;
+        if (strncmp(name + j, ext, el) == 0) {
+            if (j - i > 18) return false; // std::stoll would throw std::out_of_range: not a frame
+            long long v = 0;
+            for (size_t k = i; k < j; ++k) v = v * 10 + (name[k] - '0');
+            *out = v;
+            return true;
+        }
+        i = j;
+    }
+    return false;
+}
+
+int icpmi_discover_frames(const char *data_dir, int64_t *stamps, int64_t frames_cap, char *paths, int64_t paths_cap,
+                          int64_t *n_frames, int64_t *paths_bytes)
+{
+    if (!data_dir || !n_frames || !paths_bytes) return fail(nullptr, ICPMI_ERR_NULL, "null argument");
+    *n_frames = 0;
+    *paths_bytes = 0;
+    if (!*data_dir) return fail(nullptr, ICPMI_ERR_ARG, "empty directory name");
+    DIR *d = opendir(data_dir);
+    if (!d) return fail(nullptr, ICPMI_ERR_ARG, "Cannot open directory: %s", data_dir); // fs::directory_iterator throws
+    std::vector<std::pair<long long, std::string>> frames;
+    while (struct dirent *e = readdir(d)) {
+        const char *name = e->d_name;
+        const char *dot = strrchr(name, '.');
+        if (!dot || dot == name) continue; // path::extension() of ".ply" / "x" is empty
+        long long stamp = -1;
+        // file_utils.cpp:224-241: extension first, then the number in front of that extension's first occurrence
+        if ((strcmp(dot, ".ply") == 0 && frame_number(name, ".ply", &stamp)) ||
+            (strcmp(dot, ".bin") == 0 && frame_number(name, ".bin", &stamp)))
+            frames.emplace_back(stamp, std::string(data_dir) + (data_dir[strlen(data_dir) - 1] == '/' ? "" : "/") + name);
+    }
+    closedir(d);
+    // file_utils.cpp:244-245 sorts by number only (std::sort: equal numbers in unspecified order);
+    // here equal numbers come out by path so that the result does not depend on the file system
+    std::sort(frames.begin(), frames.end());
+    int64_t bytes = 0;
+    for (auto &f : frames) bytes += (int64_t)f.second.size() + 1;
+    *n_frames = (int64_t)frames.size();
+    *paths_bytes = bytes;
+    if (!stamps && !paths) return ICPMI_OK; // sizing call
+    if (frames_cap < *n_frames || paths_cap < bytes)
+        return fail(nullptr, ICPMI_ERR_CAPACITY, "%lld frames / %lld path bytes do not fit", (long long)*n_frames, (long long)bytes);
+    char *w = paths;
+    for (size_t i = 0; i < frames.size(); ++i) {
+        if (stamps) stamps[i] = frames[i].first;
+        if (paths) {
+            memcpy(w, frames[i].second.c_str(), frames[i].second.size() + 1);
+            w += frames[i].second.size() + 1;
+        }
+    }
+    return ICPMI_OK;
+}
+
+int icpmi_upload_points_f32(icpmi_ctx *ctx, const float *records, int64_t n, int32_t stride_floats, double *d_out_xyz)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!records || !d_out_xyz) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n < 0 || n > 700000000) return fail(ctx, ICPMI_ERR_ARG, "n out of range");
+    if (stride_floats < 3 || stride_floats > 64) return fail(ctx, ICPMI_ERR_ARG, "stride %d outside [3,64]", stride_floats);
+    if (n == 0) return ICPMI_OK;
+    const size_t bytes = sizeof(float) * (size_t)stride_floats * (size_t)n;
+    if ((rc = reserve(ctx, ctx->f32_stage, bytes))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->f32_stage.p, records, bytes, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)ctx->f32_stage.p, (int)n,
+                       (int)stride_floats, d_out_xyz);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return ICPMI_OK;
+}
+
+int icpmi_load_cloud_device(icpmi_ctx *ctx, const char *path, double *d_out_xyz, int64_t cap, int64_t *n_out)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!path || !n_out) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    *n_out = 0;
+    const size_t len = strlen(path);
+    if (len >= 4 && strcmp(path + len - 4, ".bin") == 0) {
+        FILE *f = fopen(path, "rb");
+        if (!f) return fail(ctx, ICPMI_ERR_ARG, "Cannot open file: %s", path); // file_utils.cpp:116-118
+        struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
+        fseek(f, 0, SEEK_END);
+        const long size = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        const int64_t n = size / (4 * (long)sizeof(float)); // file_utils.cpp:127
+        *n_out = n;
+        if (!d_out_xyz) return ICPMI_OK;
+        if (cap < n) return fail(ctx, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %lld", (long long)cap, (long long)n);
+        if (n == 0) return ICPMI_OK;
+        std::vector<float> rec(4 * (size_t)n, 0.f); // (a short read leaves zeros, like the host loader)
+        if (fread(rec.data(), 4 * sizeof(float), (size_t)n, f) != (size_t)n) { /* zeros stay */ }
+        return icpmi_upload_points_f32(ctx, rec.data(), n, 4, d_out_xyz);
+    }
+    // PLY: header rules and the ASCII payload are host work (icpmi_load_cloud); fp64 rows go up as they are
+    int64_t n = 0;
+    if ((rc = icpmi_load_cloud(path, nullptr, 0, &n))) return fail(ctx, rc, "%s", icpmi_last_error(nullptr));
+    *n_out = n;
+    if (!d_out_xyz) return ICPMI_OK;
+    if (cap < n) return fail(ctx, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %lld", (long long)cap, (long long)n);
+    if (n == 0) return ICPMI_OK;
+    std::vector<double> host(3 * (size_t)n);
+    if ((rc = icpmi_load_cloud(path, host.data(), n, &n))) return fail(ctx, rc, "%s", icpmi_last_error(nullptr));
+    HIP_TRY(ctx, hipMemcpy(d_out_xyz, host.data(), sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
+    return ICPMI_OK;
+}
+
+int icpmi_estimate_normals_rows(icpmi_ctx *ctx, const double *points_xyz, int64_t n, int32_t k, int64_t row0,
+                                int64_t row1, double *normals_xyz)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!points_xyz || !normals_xyz) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n <= 0) return fail(ctx, ICPMI_ERR_EMPTY_TARGET, "empty cloud");
+    if (n > (int64_t)700000000) return fail(ctx, ICPMI_ERR_ARG, "cloud larger than 7e8 points");
+    if (k < 1 || k > 64) return fail(ctx, ICPMI_ERR_ARG, "k %d outside [1,64]", k);
+    if (row0 < 0 || row1 < row0 || row1 > n) return fail(ctx, ICPMI_ERR_ARG, "rows [%lld,%lld) outside [0,%lld)", (long long)row0, (long long)row1, (long long)n);
+    if (row1 == row0) return ICPMI_OK;
+    const int m = (int)n, rows = (int)(row1 - row0);
+    if ((rc = reserve(ctx, ctx->stage_c, sizeof(double) * 3 * (size_t)m))) return rc;
+    if ((rc = reserve(ctx, ctx->nrm, sizeof(double) * 3 * (size_t)m))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.p, points_xyz, sizeof(double) * 3 * (size_t)m, hipMemcpyHostToDevice, s));
+    // a slice is always taken in point order (what a rank of a caller-sharded job wants back)
+    const bool keep_pruned = ctx->nn_pruned;
+    if ((rc = prepare_nn(ctx, (const double *)ctx->stage_c.p, m, m))) return rc;
+    ctx->nn_pruned = false;
+    rc = launch_normals(ctx, (const double *)ctx->stage_c.p, m, k, (int)row0, (int)row1, (double *)ctx->nrm.p, false, true);
+    ctx->nn_pruned = keep_pruned;
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(normals_xyz, (const double *)ctx->nrm.p + 3 * (size_t)row0, sizeof(double) * 3 * (size_t)rows,
+                                hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    harvest_profile(ctx);
+    return ICPMI_OK;
+}
+
+// ---- odometry stream: the registration part of SlamNode::process_frame (slam_node.cpp:122-152) ---------
+int icpmi_stream_reset(icpmi_ctx *ctx)
+{
+    if (!ctx) return ICPMI_ERR_NULL;
+    ctx->stream_prev_n = -1;
+    return ICPMI_OK;
+}
+
+int icpmi_stream_push(icpmi_ctx *ctx, const double *d_raw_xyz, int64_t n_raw, double voxel_size, int64_t min_points,
+                      const icpmi_config *cfg, icpmi_result *result, double *error_history, int32_t history_cap,
+                      icpmi_stream_info *info)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!d_raw_xyz || !cfg || !result || !error_history || !info) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n_raw <= 0 || n_raw > 700000000) return fail(ctx, ICPMI_ERR_ARG, "n_raw out of range");
+    if (cfg->max_iterations < 0) return fail(ctx, ICPMI_ERR_ARG, "max_iterations < 0");
+    if (history_cap < cfg->max_iterations + 1)
+        return fail(ctx, ICPMI_ERR_CAPACITY, "error_history holds %d entries, needs %d", history_cap, cfg->max_iterations + 1);
+    memset(result, 0, sizeof(*result));
+    for (int i = 0; i < 16; ++i) result->transformation[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    memset(info, 0, sizeof(*info));
+    // curr = voxel_downsample(raw)  (slam_node.cpp:122), into the buffer that is not the previous frame
+    if ((rc = reserve(ctx, ctx->stream_cur, sizeof(double) * 3 * (size_t)n_raw))) return rc;
+    int64_t n_cur = 0;
+    if ((rc = voxel_downsample_device(ctx, d_raw_xyz, (int)n_raw, voxel_size, (double *)ctx->stream_cur.p, n_raw, &n_cur))) return rc;
+    info->n_filtered = n_cur;
+    info->n_target = ctx->stream_prev_n < 0 ? 0 : ctx->stream_prev_n;
+    if (ctx->stream_prev_n < 0) {
+        info->status = ICPMI_STREAM_FIRST_FRAME;          // slam_node.cpp:69-72: nothing to register against yet
+    } else if (n_cur < min_points || n_cur <= 0 || ctx->stream_prev_n <= 0) { // (an empty cloud on either side is UB in the reference)
+        info->status = ICPMI_STREAM_TOO_FEW_POINTS;       // slam_node.cpp:125-130: the caller repeats its last pose
+    } else {
+        // source = curr, target = prev (slam_node.cpp:132-133): both already in HBM; the target's
+        // search structure and normals are built from the resident copy
+        info->status = ICPMI_STREAM_REGISTERED;
+        if ((rc = align_device(ctx, (const double *)ctx->stream_cur.p, n_cur, (const double *)ctx->stream_prev.p,
+                               ctx->stream_prev_n, cfg, result, error_history, history_cap)))
+            return rc;
+    }
+    std::swap(ctx->stream_prev, ctx->stream_cur);         // prev_points_ = curr (slam_node.cpp:128,152), no copy
+    ctx->stream_prev_n = n_cur;
     return ICPMI_OK;
 }
 

@@ -15,6 +15,20 @@
 
 namespace icpmi {
 
+// float32 records (x, y, z first, `stride` floats apart: 4 for a KITTI .bin, file_utils.cpp:126-138)
+// -> the library's N x 3 fp64 layout.  The widening that load_bin does on the host
+// (static_cast<double>, exact) done where the points are going to live: 16 B per point cross the
+// PCIe link instead of 24.
+__global__ __launch_bounds__(256) void k_widen_f32(const float *__restrict__ rec, int n, int stride,
+                                                   double *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[3 * i] = (double)rec[(size_t)i * stride];
+    out[3 * i + 1] = (double)rec[(size_t)i * stride + 1];
+    out[3 * i + 2] = (double)rec[(size_t)i * stride + 2];
+}
+
 __global__ __launch_bounds__(256) void k_voxel_keys(const double *__restrict__ pts, int n, double voxel,
                                                     long long kx0, long long ky0, long long kz0,
                                                     unsigned long long *__restrict__ keys,

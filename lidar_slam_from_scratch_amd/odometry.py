@@ -128,6 +128,50 @@ def run_odometry_device(raw_frames, ctx, voxel=0.5, max_iterations=50, tolerance
     return track
 
 
+def run_odometry_stream(paths, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6, min_points=1000):
+    """The same loop over frame FILES with everything but the file read on the device: each
+    scan goes from disk to HBM (`.bin`: float32 records, widened there), then one
+    `icpmi_stream_push` per frame does slam_node.cpp:122-152 -- voxel filter, min-points guard,
+    registration against the previous filtered scan that stayed resident -- and this function
+    applies the reference's gate and pose update (slam_node.cpp:139-142).  torch is used for the
+    raw-scan buffer only."""
+    import torch
+    from . import capi
+    track = OdometryTrack()
+    cfg = capi.Context.make_config(max_iterations=max_iterations, tolerance=tolerance)
+    ctx.stream_reset()
+    raw = None
+    for k, path in enumerate(paths):
+        t0 = time.perf_counter()
+        n = ctx.load_cloud_device_rows(path)
+        if raw is None or raw.shape[0] < n:
+            raw = torch.empty((max(n, 1) * 5 // 4, 3), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()          # the library's stream is not torch's (include/icp_mi355x.h)
+        n = ctx.load_cloud_device(path, raw.data_ptr(), raw.shape[0])
+        res, _hist, info = ctx.stream_push(raw.data_ptr(), n, voxel, min_points, cfg)
+        if info.status == capi.STREAM_FIRST_FRAME:
+            continue
+        if info.status == capi.STREAM_TOO_FEW_POINTS:            # slam_node.cpp:125-130
+            track.poses.append(track.poses[-1].copy())
+            track.deltas.append(np.eye(4))
+            track.final_errors.append(float("nan"))
+            track.iterations.append(0)
+            track.converged.append(False)
+            track.gated.append(True)
+            track.frame_ms.append(1e3 * (time.perf_counter() - t0))
+            continue
+        bad = (not res.converged) or res.final_error > 1.0        # slam_node.cpp:139-140
+        delta = np.eye(4) if bad else np.array(res.transformation[:]).reshape(4, 4)
+        track.poses.append(track.poses[-1] @ delta)                # slam_node.cpp:142
+        track.deltas.append(delta)
+        track.final_errors.append(res.final_error)
+        track.iterations.append(res.num_iterations)
+        track.converged.append(bool(res.converged))
+        track.gated.append(bool(bad))
+        track.frame_ms.append(1e3 * (time.perf_counter() - t0))
+    return track
+
+
 def absolute_trajectory_error(track, truth_poses):
     """RMS translation error against ground-truth poses expressed relative to frame 0."""
     t0_inv = np.linalg.inv(truth_poses[0])

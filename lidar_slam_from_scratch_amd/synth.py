@@ -164,20 +164,27 @@ def voxel_centroids(points, voxel):
     return sums / counts[:, None]
 
 
-def lidar_pose(frame, step=1.0, yaw_step_deg=1.0):
+def lidar_pose(frame, step=1.0, yaw_step_deg=1.0, x0=-40.0):
+    """Pose of the sensor at `frame`: `step` metres forward per frame from x0, a slow weave and a
+    slowly growing yaw.  The defaults are the 12-frame drive of round 1; the 200-frame drive of
+    SURVEY 8d (DRIVE_200) starts further back and moves 0.6 m per frame so that it stays inside
+    the scene's walls (x in [-85, 85])."""
     yaw = np.deg2rad(yaw_step_deg) * frame * 0.25
     R = rotvec_to_matrix((0.0, 0.0, yaw))
-    origin = np.array([-40.0 + step * frame, 0.5 * np.sin(0.05 * frame), 0.0])
+    origin = np.array([x0 + step * frame, 0.5 * np.sin(0.05 * frame), 0.0])
     T = np.eye(4)
     T[:3, :3] = R
     T[:3, 3] = origin
     return T
 
 
-def lidar_frame(frame, voxel=0.5, seed=3, beams=64, azimuths=1800, range_noise=0.01):
+DRIVE_200 = dict(step=0.6, yaw_step_deg=0.5, x0=-60.0)
+
+
+def lidar_frame(frame, voxel=0.5, seed=3, beams=64, azimuths=1800, range_noise=0.01, **drive):
     """One voxel-downsampled scan of the synthetic street, in the sensor frame."""
     scene = _scene(seed)
-    T = lidar_pose(frame)
+    T = lidar_pose(frame, **drive)
     pts = _raycast(T[:3, 3], T[:3, :3], scene, beams=beams, azimuths=azimuths)
     rng = np.random.Generator(np.random.PCG64(1000 + frame))
     r = np.linalg.norm(pts, axis=1, keepdims=True)

@@ -221,3 +221,33 @@ def test_bench_starts_its_own_ranks_before_touching_the_gpu():
     launch = min(n.lineno for n in ast.walk(main) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "self_launch")
     assert launch < first_torch
     assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) and "torch" in ast.dump(n) for n in tree.body)
+
+
+def test_discover_frames_follows_the_reference_rules(tmp_path, lib):
+    """file_utils.cpp:203-247: extension .ply / .bin (exact), the leftmost run of digits that stands
+    directly in front of that extension, sorted by that number."""
+    names = ["000010.bin", "000002.bin", "frame_7.ply", "007.ply", "x12y.ply", "a1.ply.bak", "notes.txt", "12.bin.ply",
+             "3.ply.bin", ".ply", "scan_5_000123.bin", "9.PLY", "4.bin"]
+    for n in names:
+        (tmp_path / n).write_bytes(b"")
+    (tmp_path / "6.ply").mkdir()                       # directory_iterator does not ask whether it is a file
+    got = capi.discover_frames(str(tmp_path))
+    assert [(k, os.path.basename(p)) for k, p in got] == [
+        (2, "000002.bin"), (4, "4.bin"), (6, "6.ply"), (7, "007.ply"), (7, "frame_7.ply"), (10, "000010.bin"),
+        (123, "scan_5_000123.bin")]
+    assert all(os.path.dirname(p) == str(tmp_path) for _, p in got)
+    assert capi.discover_frames(str(tmp_path) + "/") == got
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    assert capi.discover_frames(str(empty)) == []
+    with pytest.raises(capi.IcpError):
+        capi.discover_frames(str(tmp_path / "missing"))
+
+
+def test_run_sequence_skips_an_absent_data_dir(tmp_path):
+    """KITTI configs take --data_dir and skip (not fail) when it is absent."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_sequence.py"), "--data_dir",
+                          str(tmp_path / "kitti" / "00" / "velodyne")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode == 0 and "absent: skipped" in out.stdout, out.stdout

@@ -1,0 +1,146 @@
+"""SURVEY section 8f rows N3 / N4 and configs C4 / C5 on the GPU: scans from disk to HBM as
+float32, the resident-frame odometry call of the C ABI, and one 125k-row shard of the 1M -> 1M
+job.  Parity targets: the host loader, the oracle-driven loop, cKDTree."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from lidar_slam_from_scratch_amd import capi, odometry, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(device=0)
+    yield c
+    c.close()
+
+
+def test_bin_goes_to_the_device_as_float32(tmp_path, ctx):
+    """icpmi_load_cloud_device: KITTI .bin (file_utils.cpp:115-141) widened on the device must be
+    the host loader's array bit for bit; PLY takes the host parser."""
+    rng = np.random.default_rng(1)
+    rec = rng.normal(size=(5003, 4)).astype(np.float32) * 40
+    rec[7, 0] = np.float32(1e-30)
+    (tmp_path / "000000.bin").write_bytes(rec.tobytes() + b"\x01\x02\x03")          # trailing partial record ignored
+    path = str(tmp_path / "000000.bin")
+    want = capi.load_cloud(path)
+    n = ctx.load_cloud_device_rows(path)
+    assert n == 5003
+    d = torch.zeros((n + 5, 3), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert ctx.load_cloud_device(path, d.data_ptr(), d.shape[0]) == n
+    got = d.cpu().numpy()
+    assert (got[:n] == want).all() and (got[n:] == 0).all()
+    assert (want == rec[:, :3].astype(np.float64)).all()
+    with pytest.raises(capi.IcpError):
+        ctx.load_cloud_device(path, d.data_ptr(), 10)                               # capacity
+    with pytest.raises(capi.IcpError):
+        ctx.load_cloud_device(str(tmp_path / "nope.bin"), d.data_ptr(), d.shape[0])
+    # generic float32 records (stride 5)
+    rec5 = rng.normal(size=(100, 5)).astype(np.float32)
+    ctx.upload_points_f32(rec5, d.data_ptr())
+    assert (d.cpu().numpy()[:100] == rec5[:, :3].astype(np.float64)).all()
+    # PLY (ASCII) through the same entry point
+    ply = tmp_path / "c.ply"
+    ply.write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+                   "end_header\n1 2 3\n4.5 5.5 6.5\n-7 8 9e-3\n")
+    assert ctx.load_cloud_device(str(ply), d.data_ptr(), d.shape[0]) == 3
+    assert (d.cpu().numpy()[:3] == capi.load_cloud(str(ply))).all()
+
+
+def test_normals_of_a_row_slice(ctx):
+    _, tgt, _ = synth.c3_uniform(12000, seed=81, perm_seed=82)
+    full = ctx.estimate_normals(tgt, 20)
+    assert (ctx.estimate_normals_rows(tgt, 20, 3000, 7000) == full[3000:7000]).all()
+    assert (ctx.estimate_normals_rows(tgt, 20, 11990, 12000) == full[11990:]).all()
+    assert ctx.estimate_normals_rows(tgt, 20, 5, 5).shape == (0, 3)
+    with pytest.raises(capi.IcpError):
+        ctx.estimate_normals_rows(tgt, 20, 10, 12001)
+
+
+def test_stream_push_is_process_frame(tmp_path, oracle):
+    """30 frames of the synthetic drive (SURVEY 8d C5 stand-in) as KITTI .bin files: discover_frames,
+    file -> HBM, icpmi_stream_push per frame.  Iteration counts, gates and poses must be those of
+    the reference loop (slam_node.cpp:118-157) driven by the oracle on the host-loaded, host-filtered
+    clouds; ATE against the known trajectory equal to the oracle's.  Then the guards."""
+    import run_sequence
+    truth = run_sequence.write_synthetic_drive(str(tmp_path), 0, 30, beams=32, azimuths=900)
+    frames = capi.discover_frames(str(tmp_path))
+    assert [k for k, _ in frames] == list(range(30))
+    paths = [p for _, p in frames]
+    ctx = capi.Context(device=0)
+    tr = odometry.run_odometry_stream(paths, ctx, voxel=0.5, min_points=1000)
+    clouds = [oracle.voxel_downsample(capi.load_cloud(p), 0.5) for p in paths]
+    rf = odometry.run_odometry(clouds, lambda s, t, mi, tol: oracle.icp_point_to_plane(s, t, mi, tol, 1e-9, nthreads=8))
+    assert tr.iterations == rf.iterations and tr.gated == rf.gated and tr.converged == rf.converged
+    assert len(tr.poses) == 30
+    for a, b in zip(tr.poses, rf.poses):
+        dt, dr = synth.pose_delta(a, b)
+        assert dt <= 1e-4 and dr <= 1e-4                       # north_star tolerance (measured ~1e-12)
+    np.testing.assert_allclose(tr.final_errors, rf.final_errors, rtol=0, atol=1e-9)
+    ate_g, ate_c = odometry.absolute_trajectory_error(tr, truth), odometry.absolute_trajectory_error(rf, truth)
+    assert abs(ate_g - ate_c) < 1e-6      # (the drive is a corridor: both loops drift alike along it)
+    # the same drive through the torch-side loop of round 1 (clouds uploaded by the caller)
+    raw = [capi.load_cloud(p) for p in paths[:8]]
+    td = odometry.run_odometry_device(raw, ctx, voxel=0.5)
+    assert td.iterations == tr.iterations[:7]
+    # guards: a frame below min_points repeats the pose and still becomes the next target (slam_node.cpp:125-130)
+    ctx.stream_reset()
+    cfg = capi.Context.make_config()
+    d = [torch.from_numpy(r).cuda() for r in raw[:3]]
+    few = np.ascontiguousarray(raw[1][np.random.default_rng(4).choice(raw[1].shape[0], 700, replace=False)])
+    tiny = torch.from_numpy(few).cuda()             # spread over the whole scan, but under min_points
+    torch.cuda.synchronize()
+    _, _, i0 = ctx.stream_push(d[0].data_ptr(), d[0].shape[0], 0.5, 1000, cfg)
+    r1, h1, i1 = ctx.stream_push(tiny.data_ptr(), tiny.shape[0], 0.5, 1000, cfg)
+    r2, h2, i2 = ctx.stream_push(d[2].data_ptr(), d[2].shape[0], 0.5, 1000, cfg)
+    assert (i0.status, i1.status, i2.status) == (capi.STREAM_FIRST_FRAME, capi.STREAM_TOO_FEW_POINTS, capi.STREAM_REGISTERED)
+    assert i1.n_filtered < 1000 and i2.n_target == i1.n_filtered and not r1.converged and len(h1) == 0
+    assert list(r1.transformation) == list(np.eye(4).reshape(16))
+    want = oracle.icp_point_to_plane(oracle.voxel_downsample(raw[2], 0.5), oracle.voxel_downsample(few, 0.5))
+    assert r2.num_iterations == want.num_iterations and abs(r2.final_error - want.final_error) < 1e-9
+    ctx.close()
+
+
+def test_c4_shard_properties(oracle):
+    """BASELINE.json configs[3]: 1M -> 1M sharded 8 ways; what ONE rank does -- a 125k-row shard of the
+    source against the whole 1M target (489 splits, 489 MB of coarse minima, the >32k-query resolve) --
+    on one GPU, through properties that need no 1M x 125k brute force on the host: index range, the
+    returned squared distance recomputed exactly, cKDTree on a 20k sample, normals of a 20k-row
+    slice against the oracle, and two iterations of the registration against the oracle loop."""
+    from scipy.spatial import cKDTree
+    src, tgt, _ = synth.c4_uniform()
+    assert tgt.shape[0] == 1_000_000
+    shard = np.ascontiguousarray(src[:125_000])
+    ctx = capi.Context(device=0)
+    idx, d2 = ctx.nearest_batch(tgt, shard)
+    assert idx.min() >= 0 and idx.max() < tgt.shape[0]
+    diff = tgt[idx] - shard
+    assert (d2 == (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]).all()
+    tree = cKDTree(tgt)
+    sel = np.random.default_rng(0).choice(shard.shape[0], 20_000, replace=False)
+    dd, ii = tree.query(shard[sel], workers=-1)
+    assert (idx[sel] == ii).all()
+    nrm = ctx.estimate_normals_rows(tgt, 20, 500_000, 520_000)
+    otree = oracle.KDTree(tgt)
+    rows = np.arange(500_000, 520_000, 40)
+    for r in rows:                                               # neighbour lists of 500 rows, then their normals
+        nb = otree.k_nearest(tgt[r], 20)
+        nbp = tgt[nb]
+        c = nbp.mean(axis=0)
+        w, V = np.linalg.eigh((nbp - c).T @ (nbp - c) / 20)
+        assert abs(abs(nrm[r - 500_000] @ V[:, 0]) - 1.0) < 1e-9 and nrm[r - 500_000][2] >= 0
+    res, hist = ctx.align(shard, tgt, capi.Context.make_config(2, 0.0, 0.0))
+    ref = oracle.icp_point_to_plane(shard, tgt, 2, 0.0, 0.0, faithful=False, nthreads=16)
+    assert res.num_iterations == ref.num_iterations == 2
+    np.testing.assert_allclose(hist, ref.error_history, rtol=0, atol=1e-9)
+    dt, dr = synth.pose_delta(np.array(res.transformation[:]).reshape(4, 4), ref.transformation)
+    assert dt <= 1e-9 and dr <= 1e-9
+    ctx.close()
