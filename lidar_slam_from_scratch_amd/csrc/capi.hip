@@ -802,8 +802,10 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
 }
 
 // voxel filter on device memory -> d_out (n_out rows); see voxel.h
+// `finish`: wait for the centroids before returning (the public entry points promise complete
+// outputs; icpmi_stream_push queues the registration behind it on the same stream instead)
 int voxel_downsample_device(icpmi_ctx *ctx, const double *d_pts, int n, double voxel, double *d_out,
-                            int64_t out_cap, int64_t *n_out)
+                            int64_t out_cap, int64_t *n_out, bool finish = true)
 {
     hipStream_t s = ctx->stream;
     int rc;
@@ -814,24 +816,15 @@ int voxel_downsample_device(icpmi_ctx *ctx, const double *d_pts, int n, double v
         *n_out = n;
         return ICPMI_OK;
     }
-    // key origin from the bounding box
+    // key origin from the bounding box, formed on the device (k_voxel_keys)
     const int bblocks = std::max(1, std::min(256, (n + 255) / 256));
     if ((rc = reserve(ctx, ctx->bbox_part, sizeof(double) * 6 * (size_t)bblocks))) return rc;
     if ((rc = reserve(ctx, ctx->nn_misc, 256))) return rc;
-    NnFrame *frame = (NnFrame *)ctx->nn_misc.p;
+    VoxelBox *box = (VoxelBox *)((char *)ctx->nn_misc.p + 192); // (offset 0 is the search's own frame of the target)
+    static_assert(sizeof(VoxelBox) == sizeof(NnFrame) && sizeof(VoxelBox) <= 64, "k_bbox_final writes an NnFrame here");
     hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_pts, n, (double *)ctx->bbox_part.p, 0);
-    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, frame);
-    NnFrame hf;
-    HIP_TRY(ctx, hipMemcpyAsync(&hf, frame, sizeof(NnFrame), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    long long k0[3];
-    for (int a = 0; a < 3; ++a) {
-        const double lo = floor(hf.lo[a] / voxel), hi = floor(hf.hi[a] / voxel);
-        if (!(lo == lo) || !(hi == hi) || hi - lo >= 2097152.0 || fabs(lo) > 4.0e18 || fabs(hi) > 4.0e18)
-            return fail(ctx, ICPMI_ERR_ARG, "voxel grid spans more than 2^21 cells on axis %d (or non-finite points)", a);
-        k0[a] = (long long)lo;
-    }
-    // keys_in | keys_out | unique ; vals_in | order | counts | offsets | runs
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, (NnFrame *)box);
+    // keys_in | keys_out | unique ; vals_in | order | counts | offsets | runs, flag
     const size_t un = (size_t)n;
     if ((rc = reserve(ctx, ctx->vox_keys, sizeof(unsigned long long) * 3 * un))) return rc;
     if ((rc = reserve(ctx, ctx->vox_vals, sizeof(unsigned) * (4 * un + 16)))) return rc;
@@ -844,19 +837,22 @@ int voxel_downsample_device(icpmi_ctx *ctx, const double *d_pts, int n, double v
     HIP_TRY(ctx, exclusive_sum_u32(nullptr, &b3, counts, offsets, (unsigned)n, s));
     size_t tmp_bytes = std::max(b1, std::max(b2, b3));
     if ((rc = reserve(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
-    hipLaunchKernelGGL(k_voxel_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_pts, n, voxel, k0[0], k0[1], k0[2],
+    hipLaunchKernelGGL(k_voxel_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_pts, n, voxel, (const VoxelBox *)box, runs_d + 1,
                        keys_in, vals_in);
     HIP_TRY(ctx, sort_pairs_u64(ctx->sort_tmp.p, &b1, keys_in, keys_out, vals_in, order, (unsigned)n, s));
     HIP_TRY(ctx, run_lengths_u64(ctx->sort_tmp.p, &b2, keys_out, (unsigned)n, uniq, counts, runs_d, s));
-    unsigned runs = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&runs, runs_d, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    unsigned runs_flag[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(runs_flag, runs_d, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s)); // the call's one round trip
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (runs_flag[1])
+        return fail(ctx, ICPMI_ERR_ARG, "voxel grid spans more than 2^21 cells on an axis (or non-finite points)");
+    const unsigned runs = runs_flag[0];
     if ((int64_t)runs > out_cap) return fail(ctx, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %u", (long long)out_cap, runs);
     HIP_TRY(ctx, exclusive_sum_u32(ctx->sort_tmp.p, &b3, counts, offsets, runs, s));
-    hipLaunchKernelGGL(k_voxel_centroids, dim3((runs + 255) / 256), dim3(256), 0, s, d_pts, (const unsigned *)order,
+    hipLaunchKernelGGL(k_voxel_centroids, dim3((runs + 3) / 4), dim3(256), 0, s, d_pts, (const unsigned *)order,
                        (const unsigned *)offsets, (const unsigned *)counts, (int)runs, d_out);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (finish) HIP_TRY(ctx, hipStreamSynchronize(s));
     *n_out = runs;
     return ICPMI_OK;
 }
@@ -1488,7 +1484,7 @@ int icpmi_stream_push(icpmi_ctx *ctx, const double *d_raw_xyz, int64_t n_raw, do
     // curr = voxel_downsample(raw)  (slam_node.cpp:122), into the buffer that is not the previous frame
     if ((rc = reserve(ctx, ctx->stream_cur, sizeof(double) * 3 * (size_t)n_raw))) return rc;
     int64_t n_cur = 0;
-    if ((rc = voxel_downsample_device(ctx, d_raw_xyz, (int)n_raw, voxel_size, (double *)ctx->stream_cur.p, n_raw, &n_cur))) return rc;
+    if ((rc = voxel_downsample_device(ctx, d_raw_xyz, (int)n_raw, voxel_size, (double *)ctx->stream_cur.p, n_raw, &n_cur, false))) return rc;
     info->n_filtered = n_cur;
     info->n_target = ctx->stream_prev_n < 0 ? 0 : ctx->stream_prev_n;
     if (ctx->stream_prev_n < 0) {

@@ -29,41 +29,84 @@ __global__ __launch_bounds__(256) void k_widen_f32(const float *__restrict__ rec
     out[3 * i + 2] = (double)rec[(size_t)i * stride + 2];
 }
 
+// The key origin (the cloud's minimum key per axis) comes from the bounding box the device has
+// just reduced: no round trip to the host for it.  `flag` (one word, read back with the run count)
+// is set when the grid cannot be keyed: non-finite points, or more than 2^21 cells on an axis.
+struct VoxelBox { // same layout as NnFrame (nn_mfma.h)
+    double lo[3], hi[3];
+};
 __global__ __launch_bounds__(256) void k_voxel_keys(const double *__restrict__ pts, int n, double voxel,
-                                                    long long kx0, long long ky0, long long kz0,
+                                                    const VoxelBox *__restrict__ box, unsigned *__restrict__ flag,
                                                     unsigned long long *__restrict__ keys,
                                                     unsigned *__restrict__ vals)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    long long k0[3];
+    bool bad = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double lo = floor(box->lo[a] / voxel), hi = floor(box->hi[a] / voxel);
+        bad |= !(lo == lo) || !(hi == hi) || hi - lo >= 2097152.0 || fabs(lo) > 4.0e18 || fabs(hi) > 4.0e18;
+        k0[a] = bad ? 0 : (long long)lo;
+    }
+    if (i == 0) *flag = bad ? 1u : 0u;
     if (i >= n) return;
-    const long long kx = (long long)floor(pts[3 * i] / voxel) - kx0;       // file_utils.cpp:177
-    const long long ky = (long long)floor(pts[3 * i + 1] / voxel) - ky0;   // file_utils.cpp:178
-    const long long kz = (long long)floor(pts[3 * i + 2] / voxel) - kz0;   // file_utils.cpp:179
-    keys[i] = ((unsigned long long)kx << 42) | ((unsigned long long)ky << 21) | (unsigned long long)kz;
+    unsigned long long key = 0ull;
+    if (!bad) {
+        const long long kx = (long long)floor(pts[3 * i] / voxel) - k0[0];       // file_utils.cpp:177
+        const long long ky = (long long)floor(pts[3 * i + 1] / voxel) - k0[1];   // file_utils.cpp:178
+        const long long kz = (long long)floor(pts[3 * i + 2] / voxel) - k0[2];   // file_utils.cpp:179
+        key = ((unsigned long long)kx << 42) | ((unsigned long long)ky << 21) | (unsigned long long)kz;
+    }
+    keys[i] = key;
     vals[i] = (unsigned)i;
 }
 
-// one thread per voxel: points summed in input order (the sort is stable), then / count
+// lane `l` (wave-uniform) of a double, through the scalar unit
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// One WAVE per voxel.  The centroid must add the voxel's points in input order (the sort is
+// stable) like file_utils.cpp:188-190, so the three sums are serial chains -- but the loads
+// need not be: 64 points of the run are fetched at once (index, then coordinates), and the
+// additions walk over them through wave-uniform lane reads (v_readlane: the operand arrives in
+// an SGPR).  A thread per voxel, two dependent loads per point, took 103 us on a 115k-point scan
+// (the voxels next to the sensor hold hundreds of points); this form is bound by the adds.
 __global__ __launch_bounds__(256) void k_voxel_centroids(const double *__restrict__ pts,
                                                          const unsigned *__restrict__ order,
                                                          const unsigned *__restrict__ offsets,
                                                          const unsigned *__restrict__ counts, int runs,
                                                          double *__restrict__ out)
 {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= runs) return;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= runs) return; // wave-uniform
     const unsigned o = offsets[r], c = counts[r];
     double cx = 0.0, cy = 0.0, cz = 0.0;
-    for (unsigned t = 0; t < c; ++t) { // file_utils.cpp:188-190
-        const unsigned i = order[o + t];
-        cx += pts[3 * i];
-        cy += pts[3 * i + 1];
-        cz += pts[3 * i + 2];
+    for (unsigned base = 0; base < c; base += 64) {
+        double x = 0.0, y = 0.0, z = 0.0;
+        if (base + lane < c) {
+            const unsigned i = order[o + base + lane];
+            x = pts[3 * (size_t)i];
+            y = pts[3 * (size_t)i + 1];
+            z = pts[3 * (size_t)i + 2];
+        }
+        const int nb = c - base < 64u ? (int)(c - base) : 64;
+        for (int u = 0; u < nb; ++u) { // file_utils.cpp:188-190, every lane forms the same sums
+            cx += readlane_f64(x, u);
+            cy += readlane_f64(y, u);
+            cz += readlane_f64(z, u);
+        }
     }
-    const double k = (double)c;        // file_utils.cpp:191
-    out[3 * r] = cx / k;
-    out[3 * r + 1] = cy / k;
-    out[3 * r + 2] = cz / k;
+    if (lane == 0) {
+        const double k = (double)c;    // file_utils.cpp:191
+        out[3 * (size_t)r] = cx / k;
+        out[3 * (size_t)r + 1] = cy / k;
+        out[3 * (size_t)r + 2] = cz / k;
+    }
 }
 
 } // namespace icpmi
