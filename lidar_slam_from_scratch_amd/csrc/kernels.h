@@ -277,7 +277,9 @@ __device__ inline void step_update(IcpState *st, double *history, int final_pass
 // without any copy or event in the stream.
 __device__ __forceinline__ void publish_progress(int *progress, int ticket, int done)
 {
-    if (progress) __hip_atomic_store(progress, ticket * 2 + (done ? 1 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // relaxed: the host reads this one word only (results are read after a stream synchronisation);
+    // a release here would write the L2 back first, microseconds on every iteration's critical path
+    if (progress) __hip_atomic_store(progress, ticket * 2 + (done ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // The state is staged in LDS for the serial part: step_update touches ~100 of its words one
