@@ -58,8 +58,8 @@ typedef struct {
     int32_t device;     /* HIP device ordinal */
     int32_t normal_k;   /* neighbours for PCA normals; the reference hard-codes 20 (icp.hpp:170) */
     int32_t search;     /* ICPMI_SEARCH_* */
-    int32_t profile;    /* 0 off; 1: HIP events around the dominant kernel and the call/loop;
-                           2: around every stage (icpmi_get_profile) */
+    int32_t profile;    /* 0 off; 1: HIP events around the call, the loop and every 4th launch of the
+                           dominant kernel; 2: around every stage (icpmi_get_profile) */
 } icpmi_options;
 
 /* mirrors slam::ICPConfig, types.hpp:143-148 */
@@ -85,7 +85,7 @@ typedef struct {
  * the last icpmi_reset_profile(); only filled when options.profile != 0 */
 typedef struct {
     double nn_ms;        int64_t nn_launches;        /* correspondence search passes (coarse + resolve) */
-    double coarse_ms;    int64_t coarse_launches;    /* k_nn_coarse alone: the dominant kernel */
+    double coarse_ms;    int64_t coarse_launches;    /* k_nn_coarse alone: the dominant kernel (the launches bracketed) */
     double reduce_ms;    int64_t reduce_launches;    /* residual + 6x6 accumulation + solve */
     double transform_ms; int64_t transform_launches;
     double normals_ms;   int64_t normals_launches;   /* k-NN + PCA */
@@ -224,6 +224,10 @@ typedef struct {
 int icpmi_stream_push(icpmi_ctx *ctx, const double *d_raw_xyz, int64_t n_raw, double voxel_size,
                       int64_t min_points, const icpmi_config *cfg, icpmi_result *result,
                       double *error_history, int32_t history_cap, icpmi_stream_info *info);
+/* Same with the raw scan in host memory (uploaded once; the filtered scan still never leaves the device). */
+int icpmi_stream_push_host(icpmi_ctx *ctx, const double *raw_xyz, int64_t n_raw, double voxel_size,
+                           int64_t min_points, const icpmi_config *cfg, icpmi_result *result,
+                           double *error_history, int32_t history_cap, icpmi_stream_info *info);
 int icpmi_stream_reset(icpmi_ctx *ctx);   /* forget the resident frame (a new sequence starts) */
 
 /* Replaces ScanContext::compute (core/scan_context.hpp:44-82): 20 rings x 60 sectors max-height

@@ -1,10 +1,16 @@
 // slam_icp_adapter.hpp -- drop-in for a caller that HAS Eigen and the reference's own
 // types (slam::PointCloud / Transformation / ICPConfig / ICPResult, core/types.hpp).
 //
-// Include this INSTEAD of "slam_viz/core/icp.hpp" (it includes types.hpp itself); the two
-// call sites, slam_node.cpp:138 and loop_closure.hpp:109, stay as they are:
+// Include this INSTEAD of "slam_viz/core/icp.hpp" (it includes types.hpp itself) in BOTH places that
+// include it -- src/ros/slam_node.cpp:3 and core/loop_closure.hpp:5 (slam_node.cpp reaches the
+// latter through slam_node.hpp:18) -- the two call sites, slam_node.cpp:138 and
+// loop_closure.hpp:109, stay as they are:
 //
 //     auto result = slam::icp_point_to_plane(source, target, icp_cfg);
+//
+// Leaving one of the two includes in place puts the reference's and this definition of
+// slam::icp_point_to_plane into one translation unit: the compiler then stops with a
+// redefinition error naming both headers (there is no silent mix of the two).
 //
 // Differences from the reference implementation, by design:
 //   - any error from the library (empty cloud, HIP failure) yields
@@ -14,7 +20,8 @@
 //
 // This header cannot be compiled in the authoring image (no Eigen); it is kept free of
 // anything but the reference's public accessors: points().data(), points().rows(),
-// matrix()(r,c), Transformation(Matrix4).
+// matrix()(r,c), Transformation(Matrix4).  tests/cpp/adapter_check.cpp compiles it wherever
+// <Eigen/Dense> and a reference checkout exist (tests/test_boundary.py).
 #pragma once
 
 #include <vector>
@@ -94,6 +101,59 @@ inline PointCloud::Matrix voxel_downsample_mi355x(const PointCloud::Matrix &poin
     out.conservativeResize(rows, 3);
     return out;
 }
+
+// The registration part of SlamNode::process_frame (slam_node.cpp:122-152) as one call per frame,
+// for a node that hands over its RAW scan instead of calling voxel_downsample and
+// icp_point_to_plane itself: the filtered scan of frame t stays in device memory and is the
+// target of frame t+1 (slam_node.cpp:132-133,152), so nothing is uploaded twice.  In
+// process_frame:
+//     auto step = stream_.push(raw, config_.voxel_size, config_.min_points, icp_cfg);
+//     if (step.first_frame) { ... } else if (step.too_few_points) { repeat the last pose } else { use step.result }
+struct OdometryStream {
+    struct Step {
+        ICPResult result;            // identity / converged = false unless `registered`
+        bool registered = false;     // an ICP ran (source = this scan, target = the previous one)
+        bool first_frame = false;    // slam_node.cpp:69-72
+        bool too_few_points = false; // slam_node.cpp:125-130
+        long long filtered_points = 0;
+    };
+    Step push(const PointCloud::Matrix &raw, double voxel_size, long long min_points, const ICPConfig &config = ICPConfig())
+    {
+        Step step;
+        icpmi_ctx *ctx = icp_mi355x_detail::context();
+        if (!ctx || raw.rows() == 0) return step;
+        icpmi_config k;
+        icpmi_config_default(&k);
+        k.max_iterations = config.max_iterations;
+        k.tolerance = config.tolerance;
+        k.min_error = config.min_error;
+        const auto &M0 = config.initial_transform.matrix();
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) k.initial_transform[4 * r + c] = M0(r, c);
+        std::vector<double> hist(static_cast<size_t>(config.max_iterations > 0 ? config.max_iterations : 0) + 1);
+        icpmi_result out;
+        icpmi_stream_info info;
+        if (icpmi_stream_push_host(ctx, raw.data(), static_cast<int64_t>(raw.rows()), voxel_size, min_points, &k, &out,
+                                   hist.data(), static_cast<int32_t>(hist.size()), &info) != ICPMI_OK)
+            return step;
+        step.filtered_points = info.n_filtered;
+        step.first_frame = info.status == ICPMI_STREAM_FIRST_FRAME;
+        step.too_few_points = info.status == ICPMI_STREAM_TOO_FEW_POINTS;
+        step.registered = info.status == ICPMI_STREAM_REGISTERED;
+        if (step.registered) {
+            Transformation::Matrix4 M;
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c) M(r, c) = out.transformation[4 * r + c];
+            step.result.transformation = Transformation(M);
+            step.result.converged = out.converged != 0;
+            step.result.num_iterations = out.num_iterations;
+            step.result.final_error = out.final_error;
+            step.result.error_history.assign(hist.begin(), hist.begin() + out.history_len);
+        }
+        return step;
+    }
+    void reset() { if (icpmi_ctx *ctx = icp_mi355x_detail::context()) icpmi_stream_reset(ctx); }
+};
 
 // The facade named in BASELINE.json's north_star.
 struct ICP {

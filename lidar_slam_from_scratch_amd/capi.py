@@ -24,7 +24,7 @@ EXPORTS = [
     "icpmi_comm_init_callbacks", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
     "icpmi_scan_context", "icpmi_scan_context_distances", "icpmi_load_cloud", "icpmi_load_cloud_device",
     "icpmi_upload_points_f32", "icpmi_discover_frames", "icpmi_estimate_normals_rows",
-    "icpmi_stream_push", "icpmi_stream_reset",
+    "icpmi_stream_push", "icpmi_stream_push_host", "icpmi_stream_reset",
     "icpmi_reset_profile", "icpmi_get_profile",
 ]
 
@@ -159,6 +159,8 @@ def load_library(path=None):
     L.icpmi_estimate_normals_rows.argtypes = [vp, dp, C.c_int64, C.c_int32, C.c_int64, C.c_int64, dp]
     L.icpmi_stream_push.argtypes = [vp, vp, C.c_int64, C.c_double, C.c_int64, C.POINTER(Config), C.POINTER(Result), dp,
                                     C.c_int32, C.POINTER(StreamInfo)]
+    L.icpmi_stream_push_host.argtypes = [vp, dp, C.c_int64, C.c_double, C.c_int64, C.POINTER(Config), C.POINTER(Result), dp,
+                                         C.c_int32, C.POINTER(StreamInfo)]
     L.icpmi_stream_reset.argtypes = [vp]
     L.icpmi_scan_context.argtypes = [vp, dp, C.c_int64, dp]
     L.icpmi_scan_context_distances.argtypes = [vp, dp, dp, C.c_int64, dp]
@@ -357,6 +359,16 @@ class Context:
         res, info = Result(), StreamInfo()
         self._check(self._lib.icpmi_stream_push(self._h, C.c_void_p(raw_ptr), n_raw, float(voxel), int(min_points),
                                                 C.byref(cfg), C.byref(res), _dp(hist), cap, C.byref(info)))
+        return res, hist[:res.history_len].copy(), info
+
+    def stream_push_host(self, raw, voxel, min_points, cfg):
+        """stream_push with the raw scan in host memory (N x 3 fp64)"""
+        pts = _f64(raw)
+        cap = cfg.max_iterations + 1
+        hist = np.zeros(max(cap, 1))
+        res, info = Result(), StreamInfo()
+        self._check(self._lib.icpmi_stream_push_host(self._h, _dp(pts), pts.shape[0], float(voxel), int(min_points),
+                                                     C.byref(cfg), C.byref(res), _dp(hist), cap, C.byref(info)))
         return res, hist[:res.history_len].copy(), info
 
     def stream_reset(self):

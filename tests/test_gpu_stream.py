@@ -91,6 +91,14 @@ def test_stream_push_is_process_frame(tmp_path, oracle):
     raw = [capi.load_cloud(p) for p in paths[:8]]
     td = odometry.run_odometry_device(raw, ctx, voxel=0.5)
     assert td.iterations == tr.iterations[:7]
+    # ... and through the host-pointer form the Eigen adapter's OdometryStream uses
+    ctx.stream_reset()
+    its = []
+    for r in raw[:8]:
+        res, _, info = ctx.stream_push_host(r, 0.5, 1000, capi.Context.make_config())
+        if info.status == capi.STREAM_REGISTERED:
+            its.append(res.num_iterations)
+    assert its == tr.iterations[:7]
     # guards: a frame below min_points repeats the pose and still becomes the next target (slam_node.cpp:125-130)
     ctx.stream_reset()
     cfg = capi.Context.make_config()
