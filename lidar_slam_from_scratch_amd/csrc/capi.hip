@@ -471,15 +471,15 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                                    (float *)ctx->slotmin.p, splits, (const unsigned *)work, (const unsigned *)work_cnt,
                                    (unsigned *)nullptr, 0u, (unsigned long long *)nullptr, (const IcpState *)nullptr);
                 hipLaunchKernelGGL(k_knn_resolve<true>, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq, sorted, perm, m,
-                                   ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots, frames, knn, fb_list, fb_count,
-                                   (const int *)blk_cnt, (const int *)blk_list);
+                                   ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots, frames, (const NnFrame *)ctx->nn_misc.p, knn,
+                                   fb_list, fb_count, (const int *)blk_cnt, (const int *)blk_list);
             } else {
                 hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves>), dim3(nblk, splits),
                                    dim3(kCoarseThreads), 0, s, d_qry + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
                                    frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
                 hipLaunchKernelGGL(k_knn_resolve<false>, dim3((nq + 3) / 4), dim3(256), 0, s, d_qry, (int)c0, nq, sorted, perm, m,
-                                   ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots, frames, knn, fb_list, fb_count,
-                                   (const int *)nullptr, (const int *)nullptr);
+                                   ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots, frames, (const NnFrame *)ctx->nn_misc.p, knn,
+                                   fb_list, fb_count, (const int *)nullptr, (const int *)nullptr);
             }
         }
         hipLaunchKernelGGL(k_knn_exact_rows, dim3(1024), dim3(256), (size_t)k * 256 * (sizeof(double) + sizeof(int)),

@@ -1298,11 +1298,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
 // with exact distance <= T is collected; the k smallest by (distance, original index) are
 // written closest first -- the order kdtree.hpp:72-76 returns and icp.hpp:41-51 sums in.
 constexpr int kKnnCap = 256;        // candidates per row held in LDS (more: the bound is tightened and the row redone)
+#ifndef ICPMI_KNN_BATCH
+#define ICPMI_KNN_BATCH 2 /* 1 / 2 / 4: 431 / 435 / 432 us (the kernel is issue bound, not latency bound) */
+#endif
+constexpr int kKnnBatch = ICPMI_KNN_BATCH; // flagged slots scanned per round (their loads overlap)
+constexpr int kKnnFlagCap = 192;    // slots listed for scanning per row and attempt (a sane bound flags ~10)
 constexpr int kKnnMaxSplits = 256;  // per-split bounds cached in LDS (512k targets); beyond: recomputed
 #ifndef ICPMI_KNN_REGSLOTS
-#define ICPMI_KNN_REGSLOTS 32
+#define ICPMI_KNN_REGSLOTS 26 /* 26 -> 119 VGPRs = 4 waves per SIMD; 32 -> 129 = 3 waves: 430 vs 529 us on C3 */
 #endif
-constexpr int kKnnRegSlots = ICPMI_KNN_REGSLOTS;    // slot minima per lane kept in registers (2048 slots = 131k targets)
+constexpr int kKnnRegSlots = ICPMI_KNN_REGSLOTS;    // slot minima per lane kept in registers (1664 slots = 106k targets)
 
 // Ascending bitonic sort of one value per lane (21 compare-exchange steps); lane i ends up
 // with the i-th smallest.  Used for "k-th smallest of 64": a rank-by-counting loop costs 64
@@ -1332,6 +1337,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
                                                      const unsigned *__restrict__ perm, int m, int ms, int k,
                                                      const float *__restrict__ slotmin, int nslots,
                                                      const SplitFrame *__restrict__ frames,
+                                                     const NnFrame *__restrict__ gframe,
                                                      int *__restrict__ knn_idx /*[m][k]*/,
                                                      int *__restrict__ fb_list, int *__restrict__ fb_count,
                                                      const int *__restrict__ blk_cnt,
@@ -1341,6 +1347,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     __shared__ int cand_j[4][kKnnCap];
     __shared__ float tau_sp[4][kKnnMaxSplits]; // per-split bound on the coarse value, per row
     __shared__ int cand_r[4][kKnnCap], owner[4][kKnnCap]; // distance-only rank of a candidate; who claimed a rank
+    __shared__ int flist[4][kKnnFlagCap];                 // global numbers of the slots to scan
     __shared__ int s_list[kKnnMaxSplits];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int local = blockIdx.x * 4 + wave;
@@ -1407,6 +1414,9 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         }
         bslot = __shfl(lslot, bl, 64);
     }
+#if defined(ICPMI_KNN_STOP) && ICPMI_KNN_STOP == 1 /* timing experiment only: stop after the slot minima */
+    if (bslot >= 0) { if (lane == 0) knn_idx[(size_t)i * k] = bslot; return; }
+#endif
     // bound (b): exact scan of the best slot (kSlotTargets / 64 targets per lane); when a slot
     // is a single 64-run the 64 sorted positions after it (the next slot) also tighten the
     // bound -- those are collected later through the normal path
@@ -1449,7 +1459,11 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             }
         }
     }
-    const double t1 = __shfl(wave_sort_asc(lbest, lane), kk - 1, 64);
+    // k-th smallest of the 64 per-lane minima, sorted as fp32 rounded UP (an upper bound stays one;
+    // the fp32 network is 5 instead of 8 instructions per compare-exchange)
+    float lbf = (float)lbest;
+    lbf = (double)lbf < lbest ? __uint_as_float(__float_as_uint(lbf) + 1u) : lbf; // (lbest >= 0; Inf / NaN pass through)
+    const double t1 = (double)__shfl(wave_sort_asc(lbf, lane), kk - 1, 64);
     double T = t1;
     { // both bounds matter: on the 100k uniform cloud either one alone makes this kernel 2-3x slower
         // bound (a): k-th smallest of the 64 lane minima; the lanes at or under it (k of them, more
@@ -1475,6 +1489,9 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         T = T < dmax ? T : dmax; // (NaN rows: T becomes dmax)
     }
 
+#if defined(ICPMI_KNN_STOP) && ICPMI_KNN_STOP == 2 /* timing experiment only: stop after the bounds */
+    if (T >= 0.0) { if (lane == 0) knn_idx[(size_t)i * k] = (int)T; return; }
+#endif
     // candidates: the best slot's targets under T, then every other slot under its split's
     // bound.  If more than kKnnCap turn up, the k-th smallest of those already held is a
     // tighter valid bound: collect again with it (a few rows per cloud).
@@ -1498,53 +1515,87 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             }
             total += __popcll(km);
         }
-        // flags of the register-resident slots first (static indexing), as a bit mask
+        // Which slots to scan.  First filter, in registers: one compare per slot minimum against the
+        // bound that holds for every split (all_splits_tau).  The survivors -- a dozen of a row's
+        // 1,568 slots on the 100k cloud -- are then checked against their own split's bound and
+        // LISTED (compacted through LDS); every lane hands over one survivor per round, so the
+        // rounds number what the busiest lane holds (one to three), not the slots per lane.
+        const float tall = T >= 1.0e299 ? 3.4028235e38f : all_splits_tau(px, py, pz, *gframe, T, sq);
         unsigned regflags = 0u;
 #pragma unroll
         for (int u = 0; u < kKnnRegSlots; ++u) {
             const int e = lane + 64 * u;
-            if (e < nloc && e != bslot) {
-                const int sp = e / kCols;
-                const float tauf = sp < kKnnMaxSplits ? tau_sp[wave][sp]
-                                                      : (T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[gsplit(sp)], T, sq));
-                regflags |= sv[u] <= tauf ? (1u << u) : 0u;
-            }
+            regflags |= (e < nloc && e != bslot && sv[u] <= tall) ? (1u << u) : 0u;
         }
-#pragma unroll 1
-        for (int e0 = 0, u = 0; e0 < nloc; e0 += 64, ++u) {
-            const int e = e0 + lane;
+        int nf = 0;
+        auto list_flagged = [&](bool cand, int e) { // wave-uniform call; `cand` lanes test slot e against its split
             bool flag = false;
-            if (u < kKnnRegSlots) {
-                flag = (regflags >> u) & 1u;
-            } else if (e < nloc && e != bslot) {
+            if (cand) {
                 const int sp = e / kCols;
                 const float tauf = sp < kKnnMaxSplits ? tau_sp[wave][sp]
                                                       : (T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[gsplit(sp)], T, sq));
                 flag = mine[gslot(e)] <= tauf;
             }
-            unsigned long long pend = __ballot(flag);
-            while (pend) {
-                const int L = __ffsll((long long)pend) - 1;
-                pend &= pend - 1;
-                const int se = gslot(e0 + L);
+            const unsigned long long fm = __ballot(flag);
+            if (flag) {
+                const int pos = nf + __popcll(fm & ((1ull << lane) - 1ull));
+                if (pos < kKnnFlagCap) flist[wave][pos] = gslot(e);
+            }
+            nf += __popcll(fm);
+        };
+        while (__ballot(regflags != 0u)) {
+            const bool act = regflags != 0u;
+            const int u = act ? __ffs((int)regflags) - 1 : 0;
+            regflags &= regflags - 1u; // (0 stays 0)
+            list_flagged(act, lane + 64 * u);
+        }
+#pragma unroll 1
+        for (int e0 = 64 * kKnnRegSlots; e0 < nloc; e0 += 64) { // slots beyond the register-resident ones (> 131k targets)
+            const int e = e0 + lane;
+            const bool cand = e < nloc && e != bslot && mine[gslot(e)] <= tall;
+            if (__ballot(cand)) list_flagged(cand, e);
+        }
+        const bool overflow = nf > kKnnFlagCap; // (only with a bound that rules nothing out)
+        const int nfl = overflow ? kKnnFlagCap : nf;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int f0 = 0; f0 < nfl; f0 += kKnnBatch) {
+            constexpr int kRuns = kSlotTargets / 64;
+            double d[kKnnBatch][kRuns];
+            int jj[kKnnBatch][kRuns];
+#pragma unroll
+            for (int q = 0; q < kKnnBatch; ++q) {
+                const int f = f0 + q;
+                const int se = flist[wave][f < nfl ? f : nfl - 1];
                 const int j0 = (se / kCols) * kSplitTargets + (se % kCols) * kSlotTargets;
 #pragma unroll
-                for (int o = 0; o < kSlotTargets; o += 64) {
-                    const int jj = j0 + o + lane;
-                    double d = kInf;
-                    if (jj < m) d = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), px, py, pz);
-                    const bool keep = d <= T;
+                for (int o = 0; o < kRuns; ++o) {
+                    jj[q][o] = j0 + 64 * o + lane;
+                    d[q][o] = kInf;
+                    if (f < nfl && jj[q][o] < m)
+                        d[q][o] = sqdist(ICPMI_SX(sorted, ms, jj[q][o]), ICPMI_SY(sorted, ms, jj[q][o]), ICPMI_SZ(sorted, ms, jj[q][o]),
+                                         px, py, pz);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kKnnBatch; ++q)
+#pragma unroll
+                for (int o = 0; o < kRuns; ++o) {
+                    const bool keep = d[q][o] <= T;
                     const unsigned long long km = __ballot(keep);
                     if (keep) {
                         const int pos = total + __popcll(km & ((1ull << lane) - 1ull));
                         if (pos < kKnnCap) {
-                            cand_d[wave][pos] = d;
-                            cand_j[wave][pos] = (int)perm[jj];
+                            cand_d[wave][pos] = d[q][o];
+                            cand_j[wave][pos] = (int)perm[jj[q][o]];
                         }
                     }
                     total += __popcll(km);
                 }
-            }
+        }
+        if (overflow && total <= kKnnCap) { // unlisted slots and too few candidates to tighten the bound from
+            total = kKnnCap + 1;            // -> the exact kernel takes the row
+            break;
         }
         if (total <= kKnnCap) break;
         // k-th smallest of the kKnnCap candidates held (all real targets): new bound
@@ -1568,6 +1619,9 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         if (!(tnew < T)) break; // cannot tighten (e.g. hundreds of coincident points)
         T = tnew;
     }
+#if defined(ICPMI_KNN_STOP) && ICPMI_KNN_STOP == 3 /* timing experiment only: stop after collecting candidates */
+    if (total >= 0) { if (lane == 0) knn_idx[(size_t)i * k] = total; return; }
+#endif
     if (total > kKnnCap) { // still too many targets under the bound: hand the row to the exact kernel
         if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = i;
         return;
