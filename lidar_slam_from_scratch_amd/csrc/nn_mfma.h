@@ -435,6 +435,11 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.f;
 
+#if defined(ICPMI_COARSE_PRIO) && ICPMI_COARSE_PRIO == 1 /* A/B: static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4) */
+    if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+#elif defined(ICPMI_COARSE_PRIO) && ICPMI_COARSE_PRIO == 2
+    if (wave & 1) __builtin_amdgcn_s_setprio(1);
+#endif
     // B operands: 2 chunks of 32 tiles through one 32 KiB LDS buffer
     const uint4 *src = Bpack + (size_t)s * (kSplitTiles * 64);
 #pragma unroll 1

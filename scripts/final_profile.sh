@@ -1,14 +1,16 @@
 #!/bin/bash
 # Round-end measurement set, run on the GPU box: bench line, kernel stats of the same command,
-# PMC passes (one counter group per pass), secondary workloads.  Output under gpurun_out/final/.
+# PMC passes (one counter group per pass), secondary workloads.  Output under gpurun_out/final/;
+# the summaries are then copied into profiles/<round>/ (see profiles/README.md).
 cd "$GRAFT_REPO_ROOT"
 O="$GRAFT_REPO_ROOT/gpurun_out/final"
 mkdir -p "$O"
 set -x
-timeout -k 10 300 python bench.py > "$O/bench.json" 2> "$O/bench.err" || exit 1
+timeout -k 10 400 python bench.py > "$O/bench.json" 2> "$O/bench.err" || exit 1
+timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --no-pruned-extra > "$O/bench_20.json" 2> "$O/bench_20.err" || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline > "$O/stats.log" 2>&1 || exit 1
-for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-traffic > "$O/stats.log" 2>&1 || exit 1
+for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM"; do
     tag=$(echo "$grp" | cut -d' ' -f1 | tr 'A-Z' 'a-z')
     timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d "$O/pmc_$tag" -- python3 "$GRAFT_REPO_ROOT/scripts/run_align_once.py" 0 100000 30 2 > "$O/pmc_$tag.log" 2>&1 || exit 1
 done
@@ -18,5 +20,12 @@ timeout -k 10 200 python scripts/engine_compare.py > "$O/engines_100k.json" 2>&1
 timeout -k 10 300 python scripts/engine_compare.py 1000000 5 > "$O/engines_1m.json" 2>&1 || exit 1
 timeout -k 10 300 python scripts/shard_overhead.py > "$O/shard_overhead.json" 2>&1 || exit 1
 timeout -k 10 300 python scripts/engine_compare_lidar.py > "$O/engines_lidar_raw.json" 2>&1 || exit 1
+timeout -k 10 100 python scripts/event_overhead.py > "$O/event_overhead.txt" 2>&1 || exit 1
+# C5 at stream length: 200 synthetic frames as KITTI .bin, file -> pose, with the oracle loop beside it
+timeout -k 10 600 python scripts/run_sequence.py --make-synthetic /tmp/drive200 --frames 0:200 --oracle > "$O/sequence_200.json" 2> "$O/sequence_200.err" || exit 1
+# the small-cloud regime: kernel time against wall per frame
+mkdir -p "$O/small"
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/small/stats" -- python3 "$GRAFT_REPO_ROOT/scripts/run_sequence.py" --data_dir /tmp/drive200 --frames 0:40 > "$O/small/sequence_40_under_rocprof.json" 2> "$O/small/stats.err") || exit 1
+timeout -k 10 300 python scripts/run_sequence.py --data_dir /tmp/drive200 --frames 0:40 > "$O/small/sequence_40.json" 2> "$O/small/sequence_40.err" || exit 1
 python scripts/prof_summary.py "$O" > "$O/summary.txt" 2>&1
 echo done
