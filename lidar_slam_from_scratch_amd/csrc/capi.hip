@@ -261,6 +261,31 @@ void harvest_profile(icpmi_ctx *ctx)
 
 // ---- kernel launch wrappers ------------------------------------------------------------
 
+// Smallest target for which AUTO takes the MFMA engine (and its k-NN path).  The environment
+// variable ICPMI_MFMA_MIN_TARGETS overrides it (tuning runs); both engines return the same answers.
+// Round 1 had 8192 here, chosen on the 1-NN pass alone; the exact k-NN kernel (one thread per row,
+// serial over the targets) costs 2.3 us per target point, so a 7.4k-point frame spent 17.6 ms in
+// normal estimation where the MFMA path takes 0.2 ms (scripts/threshold_sweep.py: 1.5k points
+// 4.15 -> 0.39 ms per registration, 8k points 17.7 -> 0.44 ms).
+// The MFMA engine still wins at 300 points (1.5 vs 2.6 ms for 50 iterations, 0.2 vs 0.8 ms of
+// normals); below 256 targets a split is mostly padding and the exact kernels are kept.
+#ifndef ICPMI_MFMA_MIN_TARGETS
+#define ICPMI_MFMA_MIN_TARGETS 256
+#endif
+constexpr int kMfmaMinQueries = 64;
+int mfma_min_targets()
+{
+    static const int v = [] {
+        if (const char *e = getenv("ICPMI_MFMA_MIN_TARGETS")) {
+            char *end = nullptr;
+            const long x = strtol(e, &end, 10);
+            if (end != e && *end == '\0' && x >= 64 && x <= 100000000) return (int)x;
+        }
+        return (int)(ICPMI_MFMA_MIN_TARGETS);
+    }();
+    return v;
+}
+
 // Choose and prepare the search engine for a target cloud (once per call: the target does
 // not move).  Both engines return the same indices; AUTO takes the MFMA engine once the
 // pair count makes its fixed costs (Morton sort, operand packing, resolve) worthwhile.
@@ -268,7 +293,7 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
 {
     int engine = ctx->opt.search;
     if (engine == ICPMI_SEARCH_AUTO)
-        engine = (m >= 4 * kSplitTargets && n_hint >= 1024) ? ICPMI_SEARCH_MFMA_BF16 : ICPMI_SEARCH_EXACT_F64;
+        engine = (m >= mfma_min_targets() && n_hint >= kMfmaMinQueries) ? ICPMI_SEARCH_MFMA_BF16 : ICPMI_SEARCH_EXACT_F64;
     // the pruned engine is the MFMA engine plus block/split culling inside the ICP loop; the
     // stand-alone searches (nearest_batch, normals) have no previous neighbour to bound with
     ctx->nn_pruned = engine == ICPMI_SEARCH_MFMA_PRUNED;
@@ -430,7 +455,7 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
     hipStream_t s = ctx->stream;
     constexpr int BLOCK = 128;
     const size_t smem = (size_t)k * BLOCK * (sizeof(double) + sizeof(int));
-    const bool mfma = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= 4 * kSplitTargets;
+    const bool mfma = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= mfma_min_targets();
     const unsigned *perm = mfma ? (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m : nullptr;
     const double *qsep = d_qry == d_pts ? nullptr : d_qry; // the exact kernels read rows from d_pts unless told otherwise
     if (by_sorted_row && (!mfma || qsep)) return fail(ctx, ICPMI_ERR_ARG, "sorted-row lists need the MFMA engine's sorted target");
@@ -512,7 +537,7 @@ int launch_normals(icpmi_ctx *ctx, const double *d_pts, int m, int k, int row0, 
     Range range("icpmi:normals");
     StageTimer t(ctx, ST_NORMALS);
     if ((rc = launch_knn(ctx, d_pts, m, d_pts, m, k, row0, row1, by_sorted_row))) return rc;
-    const bool mfma = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= 4 * kSplitTargets;
+    const bool mfma = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= mfma_min_targets();
     const unsigned *perm = mfma ? (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m : nullptr;
     hipLaunchKernelGGL(k_normals_from_knn, dim3((rows + 255) / 256), dim3(256), 0, ctx->stream, d_pts, m, k, row0, row1,
                        (const int *)ctx->knn_idx.p, d_normals, by_sorted_row ? perm : (const unsigned *)nullptr,
@@ -642,7 +667,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     const bool sharded = ctx->comm != nullptr || ctx->cb_allreduce != nullptr; // exchanges on, even for 1 rank
     // pruned engine: rows are taken in the target's Morton order, so that a block's neighbours
     // lie in few splits (launch_normals); a rank's slice is then a range of sorted positions
-    const bool sorted_rows = fused && ctx->nn_pruned && ctx->opt.normal_k <= 32 && m >= 4 * kSplitTargets;
+    const bool sorted_rows = fused && ctx->nn_pruned && ctx->opt.normal_k <= 32 && m >= mfma_min_targets();
     if (sharded) {
         int per = (m + ctx->n_ranks - 1) / ctx->n_ranks;
         if (sorted_rows) per = (per + kCoarseQueries - 1) / kCoarseQueries * kCoarseQueries; // whole blocks (and slots) per rank
@@ -1061,7 +1086,7 @@ int icpmi_estimate_normals(icpmi_ctx *ctx, const double *points_xyz, int64_t n, 
     hipStream_t s = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.p, points_xyz, sizeof(double) * 3 * (size_t)m, hipMemcpyHostToDevice, s));
     if ((rc = prepare_nn(ctx, (const double *)ctx->stage_c.p, m, m))) return rc;
-    const bool sorted_rows = ctx->nn_pruned && ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= 4 * kSplitTargets;
+    const bool sorted_rows = ctx->nn_pruned && ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= mfma_min_targets();
     if ((rc = launch_normals(ctx, (const double *)ctx->stage_c.p, m, k, 0, m, (double *)ctx->nrm.p, sorted_rows, true))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(normals_xyz, ctx->nrm.p, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));

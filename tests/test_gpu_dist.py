@@ -92,11 +92,11 @@ def _worker(rank, world, port, out_dir, npts=3001, search=0):
 
 @pytest.mark.parametrize("world,npts", [(2, 3001), (3, 3001), (2, 12001)])
 def test_sharded_align_on_one_gpu(tmp_path, oracle, gpu_ctx, world, npts):
-    """npts = 12001 is past the size where AUTO picks the MFMA engine, so the sharded path
+    """npts = 12001 spans several 2048-target splits, so the sharded path
     also covers the Morton pre-pass, row-sliced MFMA normals and their all-gather -- and, with
     the pruned engine, slices of SORTED rows gathered and scattered back to point order."""
     from lidar_slam_from_scratch_amd import capi
-    # exact_f64 context -> AUTO in the workers (MFMA engine from 8192 points), the others forced
+    # exact_f64 context -> AUTO in the workers (MFMA engine from 256 target points), the others forced
     search = {"exact_f64": capi.SEARCH_AUTO, "mfma_bf16": capi.SEARCH_MFMA_BF16,
               "mfma_pruned": capi.SEARCH_MFMA_PRUNED}[gpu_ctx.engine]
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), npts, search), nprocs=world, join=True)
