@@ -340,23 +340,31 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
 
 // when d_nrm/d_partials are given the resolve kernel also does k_reduce's work (one partial
 // row per resolve workgroup: resolve_blocks(n) rows)
-// Which resolve kernel: 0 = k_nn_resolve (16 queries per wave, 64 per workgroup); W > 0 =
-// k_nn_resolve4<W> (4 queries per wave, 4 W per workgroup).  Build-time override for A/B runs.
+// Build-time overrides for A/B runs of the resolve kernels (see resolve_waves).
 #ifndef ICPMI_RESOLVE_WAVES
 #define ICPMI_RESOLVE_WAVES -1
 #endif
+#ifndef ICPMI_RESOLVE_Q32_FROM
+#define ICPMI_RESOLVE_Q32_FROM 2000000000 /* queries; above: k_nn_resolve<32>.  Off: at C3 (set to 81920) it
+                                             measured 55.7 us against 48.7 us (k_finish_step 11.7 against 13.3) */
+#endif
+// Which resolve kernel: 0 = k_nn_resolve<16> (16 queries per wave, 64 per workgroup); -32 = k_nn_resolve<32>
+// (32 per wave, 128 per workgroup); W > 0 = k_nn_resolve4<W> (4 queries per wave, 4 W per workgroup).
 int resolve_waves(int n)
 {
     if (ICPMI_RESOLVE_WAVES >= 0) return ICPMI_RESOLVE_WAVES;
     // measured (scripts/sweep_resolve*.sh, resolve + finish_step per pass, 100k targets): 8.8k / 12.5k /
     // 25k queries 34 -> 25 / 37 -> 27 / 41 -> 36 us with the quarter-wave kernel, 50k / 100k queries
     // 46 -> 52 / 63 -> 80 us (its 2-4x more partial rows and waves cost more than the shorter chains save)
-    return n <= 32768 ? 8 : 0;
+    if (n <= 32768) return 8;
+    // 32 queries per wave would put all the waves of a C3 pass on the chip at once (3,125; the 6,250 of 16
+    // per wave need a second round at 5 per SIMD) -- and lost: the longer chain per wave costs more
+    return n <= ICPMI_RESOLVE_Q32_FROM ? 0 : -32;
 }
 int resolve_blocks(int n)
 {
     const int w = resolve_waves(n);
-    const int per = w ? 4 * w : 4 * kResolveQ;
+    const int per = w > 0 ? 4 * w : (w == -32 ? 128 : 4 * kResolveQ);
     return (n + per - 1) / per;
 }
 
@@ -396,7 +404,8 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits, frames,  \
         (const NnFrame *)ctx->nn_misc.p, d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, blk_cnt, blk_list, st
     switch (resolve_waves(n)) {
-    case 0: hipLaunchKernelGGL(k_nn_resolve, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
+    case 0: hipLaunchKernelGGL(k_nn_resolve<16>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
+    case -32: hipLaunchKernelGGL(k_nn_resolve<32>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     case 4: hipLaunchKernelGGL(k_nn_resolve4<4>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     case 8: hipLaunchKernelGGL(k_nn_resolve4<8>, dim3(resolve_blocks(n)), dim3(512), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     default: hipLaunchKernelGGL(k_nn_resolve4<16>, dim3(resolve_blocks(n)), dim3(1024), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;

@@ -876,13 +876,13 @@ __device__ __forceinline__ void scan_range(const double *__restrict__ sorted,
 }
 
 // Phase 3 of both resolve kernels: the certificate.  A query's list of evaluated splits is
-// shared by GROUP lanes (the 4 quarter-lanes of a query in k_nn_resolve: GROUP = 4, lane offset
-// `sub` = quarter; the 16 lanes of a quarter in k_nn_resolve4: GROUP = 16, sub = ql).  First a
+// shared by GROUP lanes (the 64 / Q sub-lanes of a query in k_nn_resolve<Q>, lane offset `sub`;
+// the 16 lanes of a quarter in k_nn_resolve4: GROUP = 16, sub = ql, Q = 4 queries per wave).  First a
 // cheap pass: one 4-byte load and one compare against all_splits_tau per (query, split), the
 // survivors remembered as bits.  Only they -- the query's own split and the odd neighbour, 1-3
 // of 49 on the 100k cloud -- get the per-split bound (frame loads + ~40 fp64 operations), and
 // the slots or splits under it are scanned exactly by the whole wave.
-template <int GROUP>
+template <int GROUP, int Q>
 __device__ __forceinline__ void resolve_certify(const int lane, const int sub, const bool valid, const int ic, const int n,
                                                 const double px, const double py, const double pz,
                                                 const float2 *__restrict__ coarse, const int *__restrict__ slist,
@@ -940,7 +940,8 @@ __device__ __forceinline__ void resolve_certify(const int lane, const int sub, c
                 if (w) scan_range(sorted, perm, m, ms, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
                 else scan_range(sorted, perm, m, ms, sL * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
                 // every lane that holds this query takes the result
-                const bool mine = GROUP == 4 ? (lane & 15) == (L & 15) : (lane >> 4) == (L >> 4);
+                // (Q queries per wave laid out as lane % Q, or one query per quarter-wave when Q == 4)
+                const bool mine = Q == 4 ? (lane >> 4) == (L >> 4) : (lane & (Q - 1)) == (L & (Q - 1));
                 if (mine && (d < bd || (d == bd && j < bj))) {
                     bd = d;
                     bj = j;
@@ -954,11 +955,10 @@ __device__ __forceinline__ void resolve_certify(const int lane, const int sub, c
     }
 }
 
-// One wave resolves 16 queries.  Lane = (query ql = lane&15, quarter = lane>>4): the four
-// quarters share the bookkeeping of a query (each looks at a quarter of the splits) and each
-// quarter-wave scans one winning slot at a time (lane ql takes sorted positions ql, ql+16, ...
-// of the slot: three coalesced streams), so 4 slots are in flight per wave and ~6 waves per
-// SIMD hide the latency.
+// One wave resolves 16 (or 32) queries.  Lane = (query ql, sub-lane): the sub-lanes share the
+// bookkeeping of a query (each looks at its share of the splits) and each quarter-wave scans one
+// winning slot at a time (lane l16 takes sorted positions l16, l16+16, ... of the slot: three
+// coalesced streams), so 4 slots are in flight per wave.
 constexpr int kResolveQ = 16;
 // Waves per SIMD the register allocation must allow (A/B knob).  The kernel waits on memory three
 // quarters of the time (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.77) and, at 64 queries per workgroup, C3
@@ -974,6 +974,11 @@ constexpr int kResolveQ = 16;
 #define ICPMI_RESOLVE_RUNROLL 4
 #endif
 
+// Q = queries per wave, 16 or 32: lane = (query ql = lane % Q, sub = lane / Q); the 64 / Q sub-lanes
+// of a query share its bookkeeping.  Q = 32 halves the waves of a pass (C3: 3,125, all resident
+// at once, where the 6,250 of Q = 16 need a second round at 5 waves per SIMD) at the price of a
+// longer chain per wave (8 scan rounds instead of 4).
+template <int Q>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOLVE_OCC, 8))) void k_nn_resolve(
     const double *__restrict__ qry, int n,
                                                     const double *__restrict__ sorted,
@@ -990,13 +995,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
                                                     const int *__restrict__ blk_list,
                                                     const IcpState *__restrict__ st)
 {
+    static_assert(Q == 16 || Q == 32, "queries per wave");
+    constexpr int SUBS = 64 / Q;   // lanes per query
+    constexpr int ROUNDS = Q / 4;  // phase 2: four quarter-waves scan four slots per round
     if (st && st->done) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ql = lane & 15, quarter = lane >> 4;
-    const int qbase = (blockIdx.x * 4 + wave) * kResolveQ;
-    // pruned engine: only the splits on the query block's list were evaluated (the 16 queries
+    const int ql = lane & (Q - 1), sub = lane / Q;
+    const int l16 = lane & 15, quarter = lane >> 4;
+    const int qbase = (blockIdx.x * 4 + wave) * Q;
+    // pruned engine: only the splits on the query block's list were evaluated (the queries
     // of a wave share a block); otherwise all of them
-    static_assert(kCoarseQueries % kResolveQ == 0, "a wave's queries share a coarse block");
+    static_assert(kCoarseQueries % Q == 0, "a wave's queries share a coarse block");
     const int *slist = blk_list ? blk_list + (size_t)(qbase / kCoarseQueries) * splits : nullptr;
     const int nact = blk_list ? (qbase < n ? blk_cnt[qbase / kCoarseQueries] : 0) : splits;
     const int i = qbase + ql; // waves past the end run on a clamped query and write nothing
@@ -1004,10 +1013,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
     const int ic = valid ? i : n - 1;
     const double px = qry[3 * ic], py = qry[3 * ic + 1], pz = qry[3 * ic + 2];
 
-    // phase 1: smallest coarse value over the splits (each quarter takes every 4th split)
+    // phase 1: smallest coarse value over the splits (each sub-lane takes every SUBS-th split)
     float best = kBig;
     int bs = 0;
-    for (int e = quarter; e < nact; e += 4) {
+    for (int e = sub; e < nact; e += SUBS) {
         const int s = slist ? slist[e] : e;
         const float v = coarse[(size_t)s * n + ic].x;
         if (v < best) {
@@ -1016,7 +1025,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
         }
     }
 #pragma unroll
-    for (int x = 16; x < 64; x <<= 1) {
+    for (int x = Q; x < 64; x <<= 1) {
         const float ov = __shfl_xor(best, x, 64);
         const int os = __shfl_xor(bs, x, 64);
         if (ov < best || (ov == best && os < bs)) {
@@ -1030,11 +1039,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
     double bd = 1.7976931348623157e308;
     int bj = 0x7fffffff;
 #pragma unroll ICPMI_RESOLVE_RUNROLL
-    for (int r = 0; r < 4; ++r) {
-        const int src = quarter * 4 + r; // the query this quarter scans now (a lane of quarter 0)
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int src = quarter * ROUNDS + r; // the query this quarter scans now (a lane with sub == 0)
         const double qx = __shfl(px, src, 64), qy = __shfl(py, src, 64), qz = __shfl(pz, src, 64);
         const int s = __shfl(bs, src, 64), c = __shfl(bcol, src, 64);
-        const int j0 = s * kSplitTargets + c * kSlotTargets + ql; // lane takes ql, ql+16, ...: coalesced
+        const int j0 = s * kSplitTargets + c * kSlotTargets + l16; // lane takes l16, l16+16, ...: coalesced
         double d = 1.7976931348623157e308;
         int j = 0x7fffffff;
 #pragma unroll ICPMI_RESOLVE_UNROLL
@@ -1057,10 +1066,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
                 j = oj;
             }
         }
-        // query ql was scanned by quarter ql>>2 in round ql&3
-        const double rd = __shfl(d, (ql >> 2) * 16, 64);
-        const int rj = __shfl(j, (ql >> 2) * 16, 64);
-        if ((ql & 3) == r) {
+        // query ql was scanned by quarter ql / ROUNDS in round ql % ROUNDS
+        const double rd = __shfl(d, (ql / ROUNDS) * 16, 64);
+        const int rj = __shfl(j, (ql / ROUNDS) * 16, 64);
+        if ((ql % ROUNDS) == r) {
             bd = rd;
             bj = rj;
         }
@@ -1068,9 +1077,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
 
     // phase 3: certificate (resolve_certify)
     unsigned extra_slots = 0, extra_splits = 0;
-    resolve_certify<4>(lane, quarter, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
-                       bd, bj, extra_slots, extra_splits);
-    if (valid && quarter == 0) {
+    resolve_certify<SUBS, Q>(lane, sub, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
+                             bd, bj, extra_slots, extra_splits);
+    if (valid && sub == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
         if (d2out) d2out[i] = bd;
     }
@@ -1085,15 +1094,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
             atomicAdd(&counters[1], (unsigned long long)ef);
         }
     }
-    // fused residual + normal equations (what k_reduce does, icp.hpp:99-120,198-206): the 16
+    // fused residual + normal equations (what k_reduce does, icp.hpp:99-120,198-206): the Q
     // owners of a wave form their J row and b, the 28 sums go wave -> LDS -> one partial row
     // per workgroup, summed later in a fixed order by k_finish_step
     if (partials) {
-        // 16 rows of 28 terms per wave -> LDS (row stride 29: conflict-free), then lane l sums
-        // column l & 31 over the 8 rows of half l >> 5 and the halves meet with one exchange
-        __shared__ double jrow[4][16][29];
+        // Q rows of 28 terms per wave -> LDS (row stride 29: conflict-free), then lane l sums
+        // column l & 31 over the Q / 2 rows of half l >> 5 and the halves meet with one exchange
+        __shared__ double jrow[4][Q][29];
         __shared__ double red[4][28];
-        if (quarter == 0) { // each term goes to LDS as it is formed (28 live doubles would cost 2 waves per SIMD)
+        if (sub == 0) { // each term goes to LDS as it is formed (28 live doubles would cost 2 waves per SIMD)
             double J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, b = 0.0;
             if (valid) {
                 const int j = (unsigned)bj < (unsigned)m ? bj : 0;
@@ -1124,7 +1133,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
             double v = 0.0;
             if (c < 28) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v += jrow[wave][h * 8 + r][c];
+                for (int r = 0; r < Q / 2; ++r) v += jrow[wave][h * (Q / 2) + r][c];
             }
             v += __shfl_xor(v, 32, 64);
             if (lane < 28) red[wave][lane] = v;
@@ -1222,7 +1231,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
 
     // phase 3: certificate (resolve_certify)
     unsigned extra_slots = 0, extra_splits = 0;
-    resolve_certify<16>(lane, ql, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
+    resolve_certify<16, 4>(lane, ql, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                         bd, bj, extra_slots, extra_splits);
     if (valid && ql == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
