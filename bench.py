@@ -134,6 +134,8 @@ def main():
                     help="rehearsal on one GPU: take the multi-rank code path (process group, RCCL communicator "
                          "inside the library, sharded kernels) with a world of 1")
     ap.add_argument("--cpu-steps", type=int, default=None)
+    ap.add_argument("--force-fallback-exchange", action="store_true",
+                    help="rehearsal: pretend the library's RCCL communicator failed and exchange through torch.distributed")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N-rank run where RCCL cannot form a communicator (several ranks sharing "
                          "one GPU): process group over gloo, the library's two exchanges through host callbacks")
@@ -185,11 +187,27 @@ def main():
     # profile level 1: HIP events around the dominant kernel and the call/loop only
     # (the fp64 engine has no single dominant kernel bracket: time its whole NN pass instead)
     ctx = capi.Context(device=local_rank, search=args.search, profile=2 if args.search == 1 else 1)
+    exchange = None
     if dist is not None:
         if args.rehearse_gloo:
             icpdist.init_callbacks(ctx, dist)
         else:
-            icpdist.init_rccl(ctx, dist, device=dev, allow_single=args.force_dist)
+            # the library's own RCCL communicator; if it cannot be formed on some rank, every rank
+            # (they agree through one all-reduce) falls back to exchanging through torch's collectives
+            ok = 1.0
+            try:
+                if args.force_fallback_exchange:
+                    raise capi.IcpError(capi.ERR_RCCL, "--force-fallback-exchange")
+                icpdist.init_rccl(ctx, dist, device=dev, allow_single=args.force_dist)
+            except capi.IcpError as e:
+                sys.stderr.write("rank %d: library communicator failed (%s)\n" % (rank, e))
+                ok = 0.0
+            agreed = torch.tensor([ok], dtype=torch.float64, device=dev)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if float(agreed.item()) < 1.0:
+                exchange = "torch.distributed collectives staged through device tensors (the library's RCCL communicator could not be formed)"
+                ctx.comm_finalize()
+                icpdist.init_callbacks(ctx, dist, device=dev)
 
     def call(iters):
         cfg = capi.Context.make_config(max_iterations=iters, tolerance=0.0, min_error=0.0)
@@ -289,7 +307,7 @@ def main():
                        "source_points": int(src.shape[0]), "target_points": int(m),
                        "parallelism": ("source sharded x%d, REHEARSAL (not a scaling number): ranks share GPUs, "
                                        "exchange through gloo host callbacks" % world) if args.rehearse_gloo
-                       else "source sharded x%d, 29-double RCCL all-reduce/iter" % world
+                       else "source sharded x%d, 30-double all-reduce/iter: %s" % (world, exchange or "RCCL inside the library")
                        if dist is not None else "single GPU",
                        "search": "bf16 MFMA coarse pass over all pairs + certified fp64 resolve" if mfma
                        else "exact fp64 brute force"},

@@ -32,19 +32,32 @@ def init_rccl(ctx, dist, device=None, allow_single=False):
     ctx.comm_init(n_ranks, rank, ident[0])
 
 
-def init_callbacks(ctx, dist):
-    """Exchange through torch.distributed collectives on host tensors (e.g. gloo)."""
+def init_callbacks(ctx, dist, device=None):
+    """Exchange through torch.distributed collectives: on host tensors (gloo), or, with `device`,
+    staged through tensors on that device (a process group whose backend only moves device
+    memory, i.e. torch's own RCCL: the fallback of bench.py when the library's communicator
+    cannot be formed -- slower per exchange, same sums)."""
     import torch
     n_ranks, rank = dist.get_world_size(), dist.get_rank()
 
     def allreduce(buf):
         t = torch.from_numpy(buf)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if device is None:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:
+            d = t.to(device)
+            dist.all_reduce(d, op=dist.ReduceOp.SUM)
+            t.copy_(d.cpu())
 
     def allgather(buf, per):
         mine = torch.from_numpy(buf[rank * per:(rank + 1) * per].copy())
-        parts = [torch.empty(per, dtype=torch.float64) for _ in range(n_ranks)]
-        dist.all_gather(parts, mine)
+        if device is None:
+            parts = [torch.empty(per, dtype=torch.float64) for _ in range(n_ranks)]
+            dist.all_gather(parts, mine)
+        else:
+            parts = [torch.empty(per, dtype=torch.float64, device=device) for _ in range(n_ranks)]
+            dist.all_gather(parts, mine.to(device))
+            parts = [p.cpu() for p in parts]
         for r, p in enumerate(parts):
             buf[r * per:(r + 1) * per] = p.numpy()
 
