@@ -126,7 +126,7 @@ struct icpmi_ctx {
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
     int nn_splits = 0;
     int nn_ms = 0;                            // component stride of the SoA sorted target
-    IcpState *d_state = nullptr;
+    IcpState *d_state = nullptr;   // two of them (align_device alternates in the sharded loop)
     IcpState *h_state = nullptr;   // pinned
     int32_t *h_flags = nullptr;    // host-mapped ring: (iteration + 1) * 2 + done, written by the device
     int32_t *d_flags = nullptr;    // the same words through the device's address space
@@ -662,7 +662,10 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     hs->tolerance = cfg->tolerance;
     hs->min_error = cfg->min_error;
     hs->max_hist = max_hist;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state, hs, sizeof(IcpState), hipMemcpyHostToDevice, s));
+    // two state buffers: the sharded loop's fused step + transform kernel reads one and writes the
+    // other (k_step_transform); `st` is the one the coming kernels read
+    IcpState *st = ctx->d_state;
+    HIP_TRY(ctx, hipMemcpyAsync(st, hs, sizeof(IcpState), hipMemcpyHostToDevice, s));
 
     if ((rc = prepare_nn(ctx, d_tgt, m, n))) return rc;
     // with the MFMA engine the resolve kernel also forms the normal-equation partial sums
@@ -739,50 +742,59 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         StageTimer t(ctx, ST_TRANSFORM);
         if (pruned)
             hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, d_src, src_perm, cur, n,
-                               (const IcpState *)ctx->d_state, 1, 0, d_tgt, (const int *)nullptr, m, frames, splits,
+                               (const IcpState *)st, 1, 0, d_tgt, (const int *)nullptr, m, frames, splits,
                                blk_cnt, blk_list, work, work_cnt /* pass 0 reads counter 0 */);
         else
             hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, d_src,
-                               cur, n, ctx->d_state, 1, 0);
+                               cur, n, st, 1, 0);
     }
 
     auto iteration = [&](int final_pass, int *progress, int ticket) -> int {
         int r2;
+        const bool fuse_step = sharded && !pruned && n > 0 && !final_pass;
         if (n > 0 && fused) {
-            if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, ctx->d_state, d_tgt, nrm, partials,
+            if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, st, d_tgt, nrm, partials,
                                      pruned ? pass_no : -1))) return r2;
             ++pass_no;
         } else if (n > 0) {
-            if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, ctx->d_state))) return r2;
+            if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, st))) return r2;
         }
         {
             Range range("icpmi:reduce_solve");
             StageTimer t(ctx, ST_REDUCE);
             if (!fused)
                 hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, cur, n, d_tgt, m, nrm, idx, partials,
-                                   ctx->d_state);
+                                   st);
             if (sharded) {
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
-                                   ctx->d_state);
-                if ((r2 = exchange_allreduce(ctx, ctx->d_state->sums, kNumExchanged))) return r2;
-                hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, ctx->d_state, hist, final_pass, progress, ticket,
-                                   ctx->n_ranks);
+                                   st);
+                if ((r2 = exchange_allreduce(ctx, st->sums, kNumExchanged))) return r2;
+                if (fuse_step) { // step + pose update of this rank's rows in one launch, into the other state buffer
+                    IcpState *other = st == ctx->d_state ? ctx->d_state + 1 : ctx->d_state;
+                    hipLaunchKernelGGL(k_step_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
+                                       (const double *)cur, cur, n, (const IcpState *)st, other, hist, progress, ticket,
+                                       ctx->n_ranks);
+                    st = other;
+                } else {
+                    hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, st, hist, final_pass, progress, ticket,
+                                       ctx->n_ranks);
+                }
             } else {
                 hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
-                                   ctx->d_state, hist, final_pass, progress, ticket);
+                                   st, hist, final_pass, progress, ticket);
             }
         }
-        if (!final_pass && n > 0) {
+        if (!final_pass && n > 0 && !fuse_step) {
             Range range("icpmi:transform");
             StageTimer t(ctx, ST_TRANSFORM);
             if (pruned) // + each block's box and its exact distance bound to this iteration's neighbours
                 hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, (const double *)cur,
-                                   (const unsigned *)nullptr, cur, n, (const IcpState *)ctx->d_state, 0, 1, d_tgt,
+                                   (const unsigned *)nullptr, cur, n, (const IcpState *)st, 0, 1, d_tgt,
                                    (const int *)idx, m, frames, splits, blk_cnt, blk_list, work,
                                    work_cnt + (pass_no & 1) /* the next pass's counter */);
             else
                 hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
-                                   cur, cur, n, ctx->d_state, 0, 1);
+                                   cur, cur, n, st, 0, 1);
         }
         return ICPMI_OK;
     };
@@ -819,7 +831,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     delete t_total;
     t_total = nullptr;
 
-    HIP_TRY(ctx, hipMemcpyAsync(hs, ctx->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(hs, st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     HIP_TRY(ctx, hipGetLastError());
     const int hl = std::min(hs->hist_len, max_hist);
@@ -983,7 +995,7 @@ int icpmi_create(const icpmi_options *opt, icpmi_ctx **out)
     };
     if (hipSetDevice(o.device) != hipSuccess) return bail("hipSetDevice");
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
-    if (hipMalloc((void **)&ctx->d_state, sizeof(IcpState)) != hipSuccess) return bail("hipMalloc state");
+    if (hipMalloc((void **)&ctx->d_state, 2 * sizeof(IcpState)) != hipSuccess) return bail("hipMalloc state");
     if (hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
     if (hipHostMalloc((void **)&ctx->h_flags, sizeof(int32_t) * kFlagRing, hipHostMallocMapped) != hipSuccess) return bail("hipHostMalloc");
     memset(ctx->h_flags, 0, sizeof(int32_t) * kFlagRing);

@@ -239,13 +239,13 @@ __device__ inline void step_update(IcpState *st, double *history, int final_pass
             // evaluation, so the reference's post-loop pass (icp.hpp:235-252) recomputes
             // exactly last_error
             st->final_error = st->last_error;
-            if (st->hist_len < st->max_hist) history[st->hist_len] = st->last_error;
+            if (history && st->hist_len < st->max_hist) history[st->hist_len] = st->last_error;
             st->hist_len += 1;
         }
         return;
     }
     const double error = __dsqrt_rn(st->sums[27] / st->sums[28]);
-    if (st->hist_len < st->max_hist) history[st->hist_len] = error;
+    if (history && st->hist_len < st->max_hist) history[st->hist_len] = error;
     st->hist_len += 1;
     st->last_error = error;
     if (final_pass) {
@@ -348,6 +348,45 @@ __global__ __launch_bounds__(64) void k_step(IcpState *st, double *history, int 
     }
     __syncthreads();
     state_copy(st, &ls);
+}
+
+// multi GPU, one launch fewer per iteration: k_step and k_transform in one kernel.  Every workgroup
+// repeats the (deterministic) step from the all-reduced sums on its own LDS copy of the state --
+// the same bits in, the same bits out -- and moves its points with the update it has just formed
+// (icp.hpp:220-226); workgroup 0 alone records the history entry, publishes the progress word and
+// stores the new state.  It stores it into the OTHER of two state buffers: a workgroup that starts
+// late must still read the state of before the step, so the loop's kernels alternate between the
+// two (`sin` of one iteration is `sout` of the previous one).
+__global__ __launch_bounds__(256) void k_step_transform(const double *in, double *out, int n, const IcpState *sin,
+                                                        IcpState *sout, double *history, int *progress, int ticket,
+                                                        int n_ranks)
+{
+    __shared__ IcpState ls;
+    state_copy(&ls, sin);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ndone = ls.sums[kDoneSlot];
+        const bool all = ndone == (double)n_ranks, some = ndone > 0.0 && !all;
+        if (some) {
+            ls.error = 1;
+            ls.done = 1;
+        }
+        step_update(&ls, blockIdx.x == 0 ? history : nullptr, 0);
+        if (blockIdx.x == 0) publish_progress(progress, ticket, all || some);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) state_copy(sout, &ls);
+    if (ls.done) return; // the loop ended before or in this step: the source stays where it is (icp.hpp:210-217)
+    const double *T = ls.delta;
+    const double r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3];
+    const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
+    const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        out[3 * i] = ((x * r00 + y * r01) + z * r02) + t0;
+        out[3 * i + 1] = ((x * r10 + y * r11) + z * r12) + t1;
+        out[3 * i + 2] = ((x * r20 + y * r21) + z * r22) + t2;
+    }
 }
 
 // one-shot solve for icpmi_solve_point_to_plane (icp.hpp:89-144)
