@@ -136,3 +136,22 @@ def test_rccl_single_rank_communicator(oracle, search):
     np.testing.assert_allclose(h1, h0, rtol=0, atol=1e-12)
     assert (h2 == h0).all()
     np.testing.assert_allclose(np.array(r1.transformation[:]), np.array(r0.transformation[:]), atol=1e-12)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent starts torch.distributed.run before it
+    touches the GPU and rank 0 prints the one JSON line.  Rehearsed here with two ranks sharing this
+    box's one GPU and the host-callback exchange (RCCL refuses two ranks on one device); the real
+    N-GPU run differs in the exchange only."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-gloo", "--steps", "4",
+                          "--warmup", "1", "--points", "20000", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "REHEARSAL" in d["config"]["parallelism"] and d["roofline"]["frac"] > 0
