@@ -882,8 +882,9 @@ __device__ __forceinline__ void scan_range(const double *__restrict__ sorted,
 // survivors remembered as bits.  Only they -- the query's own split and the odd neighbour, 1-3
 // of 49 on the 100k cloud -- get the per-split bound (frame loads + ~40 fp64 operations), and
 // the slots or splits under it are scanned exactly by the whole wave.
-template <int GROUP, int Q>
-__device__ __forceinline__ void resolve_certify(const int lane, const int sub, const bool valid, const int ic, const int n,
+template <int GROUP, int Q, int KEEP>
+__device__ __forceinline__ void resolve_certify(const float (&pv)[KEEP > 0 ? KEEP : 1], // phase 1's first KEEP values per lane
+                                                const int lane, const int sub, const bool valid, const int ic, const int n,
                                                 const double px, const double py, const double pz,
                                                 const float2 *__restrict__ coarse, const int *__restrict__ slist,
                                                 const int nact, const SplitFrame *__restrict__ frames,
@@ -905,7 +906,16 @@ __device__ __forceinline__ void resolve_certify(const int lane, const int sub, c
         unsigned cmask = 0u;
         const int left = nact - base;
         const int kmax = left >= 32 * GROUP ? 32 : (left + GROUP - 1) / GROUP; // wave-uniform
-        for (int k = 0; k < kmax; ++k) {
+        int k0 = 0;
+        if (KEEP > 0 && base == 0) { // the values phase 1 already loaded: no second trip to memory for them
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                const int e = k * GROUP + sub;
+                cmask |= (e < nact && look && pv[k] <= tmax) ? (1u << k) : 0u;
+            }
+            k0 = KEEP;
+        }
+        for (int k = k0; k < kmax; ++k) {
             const int e = base + k * GROUP + sub;
             if (e < nact && look) {
                 const int s = slist ? slist[e] : e;
@@ -967,6 +977,9 @@ constexpr int kResolveQ = 16;
 #ifndef ICPMI_RESOLVE_OCC
 #define ICPMI_RESOLVE_OCC 5
 #endif
+#ifndef ICPMI_RESOLVE_KEEP
+#define ICPMI_RESOLVE_KEEP 16 /* phase-1 values per lane kept for the certificate (64 splits at 16 queries per wave) */
+#endif
 #ifndef ICPMI_RESOLVE_UNROLL
 #define ICPMI_RESOLVE_UNROLL 4
 #endif
@@ -1013,10 +1026,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
     const int ic = valid ? i : n - 1;
     const double px = qry[3 * ic], py = qry[3 * ic + 1], pz = qry[3 * ic + 2];
 
-    // phase 1: smallest coarse value over the splits (each sub-lane takes every SUBS-th split)
+    // phase 1: smallest coarse value over the splits (each sub-lane takes every SUBS-th split); the
+    // first KEEP values of a lane stay in registers for the certificate's first filter
+    constexpr int KEEP = ICPMI_RESOLVE_KEEP;
+    static_assert(KEEP <= 32, "one bit of the certificate's candidate mask per kept value");
+    float pv[KEEP > 0 ? KEEP : 1];
     float best = kBig;
     int bs = 0;
-    for (int e = sub; e < nact; e += SUBS) {
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const int e = sub + SUBS * k;
+        pv[k] = kBig;
+        if (e < nact) {
+            const int s = slist ? slist[e] : e;
+            pv[k] = coarse[(size_t)s * n + ic].x;
+            if (pv[k] < best) {
+                best = pv[k];
+                bs = s;
+            }
+        }
+    }
+    for (int e = sub + SUBS * KEEP; e < nact; e += SUBS) {
         const int s = slist ? slist[e] : e;
         const float v = coarse[(size_t)s * n + ic].x;
         if (v < best) {
@@ -1077,7 +1107,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
 
     // phase 3: certificate (resolve_certify)
     unsigned extra_slots = 0, extra_splits = 0;
-    resolve_certify<SUBS, Q>(lane, sub, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
+    resolve_certify<SUBS, Q, KEEP>(pv, lane, sub, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                              bd, bj, extra_slots, extra_splits);
     if (valid && sub == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
@@ -1180,10 +1210,26 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
     const int *slist = blk_list ? blk_list + (size_t)(qbase / kCoarseQueries) * splits : nullptr;
     const int nact = blk_list ? (qbase < n ? blk_cnt[qbase / kCoarseQueries] : 0) : splits;
 
-    // phase 1: smallest coarse value over the splits; ties to the lowest split
+    // phase 1: smallest coarse value over the splits; ties to the lowest split.  The first KEEP4
+    // values of a lane (64 splits) stay in registers for the certificate's first filter.
+    constexpr int KEEP4 = ICPMI_RESOLVE_KEEP > 0 ? 4 : 0;
+    float pv[KEEP4 > 0 ? KEEP4 : 1];
     float best = kBig;
     int bs = 0;
-    for (int e = ql; e < nact; e += 16) {
+#pragma unroll
+    for (int k = 0; k < KEEP4; ++k) {
+        const int e = ql + 16 * k;
+        pv[k] = kBig;
+        if (e < nact) {
+            const int s = slist ? slist[e] : e;
+            pv[k] = coarse[(size_t)s * n + ic].x;
+            if (pv[k] < best || (pv[k] == best && s < bs)) {
+                best = pv[k];
+                bs = s;
+            }
+        }
+    }
+    for (int e = ql + 16 * KEEP4; e < nact; e += 16) {
         const int s = slist ? slist[e] : e;
         const float v = coarse[(size_t)s * n + ic].x;
         if (v < best || (v == best && s < bs)) {
@@ -1231,7 +1277,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
 
     // phase 3: certificate (resolve_certify)
     unsigned extra_slots = 0, extra_splits = 0;
-    resolve_certify<16, 4>(lane, ql, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
+    resolve_certify<16, 4, KEEP4>(pv, lane, ql, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                         bd, bj, extra_slots, extra_splits);
     if (valid && ql == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
