@@ -98,6 +98,13 @@ struct NnFrame {     // bounding box of the whole target (Morton quantisation)
 #define ICPMI_SY(sorted, ms, j) (sorted)[(size_t)(ms) + (j)]
 #define ICPMI_SZ(sorted, ms, j) (sorted)[2 * (size_t)(ms) + (j)]
 
+// The coarse minima of the 1-NN pass are two planes of one buffer: x[split][n] (smallest column
+// minimum, tagged with its column) and y[split][n] (second smallest).  The resolve reads all of x
+// (phase 1) and only a handful of y (certificate candidates): as float2 records every 4-byte read
+// of x dragged its y along.
+#define ICPMI_CX(coarse, n, nsplits, s, i) (reinterpret_cast<const float *>(coarse))[(size_t)(s) * (n) + (i)]
+#define ICPMI_CY(coarse, n, nsplits, s, i) (reinterpret_cast<const float *>(coarse))[((size_t)(nsplits) + (s)) * (size_t)(n) + (i)]
+
 struct SplitFrame {  // per split of 2048 sorted targets
     double c[3];     // centre the split's operands are expressed about
     double rho;      // >= max |q - c| over the split (inflated)
@@ -518,7 +525,11 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
             const float hi = __builtin_fmaxf(v1, o1);
             v1 = __builtin_fminf(v1, o1);
             v2 = min3f(hi, v2, o2);
-            if (half == 0 && iq < n) coarse[(size_t)s * n + iq] = make_float2(v1, v2);
+            if (half == 0 && iq < n) {
+                float *plane = reinterpret_cast<float *>(coarse);
+                plane[(size_t)s * n + iq] = v1;
+                plane[((size_t)nsplits + s) * (size_t)n + iq] = v2;
+            }
         }
     }
 }
@@ -886,7 +897,8 @@ template <int GROUP, int Q, int KEEP>
 __device__ __forceinline__ void resolve_certify(const float (&pv)[KEEP > 0 ? KEEP : 1], // phase 1's first KEEP values per lane
                                                 const int lane, const int sub, const bool valid, const int ic, const int n,
                                                 const double px, const double py, const double pz,
-                                                const float2 *__restrict__ coarse, const int *__restrict__ slist,
+                                                const float2 *__restrict__ coarse, const int nsplits,
+                                                const int *__restrict__ slist,
                                                 const int nact, const SplitFrame *__restrict__ frames,
                                                 const NnFrame *__restrict__ gframe, const int bs,
                                                 const double *__restrict__ sorted, const unsigned *__restrict__ perm,
@@ -919,7 +931,7 @@ __device__ __forceinline__ void resolve_certify(const float (&pv)[KEEP > 0 ? KEE
             const int e = base + k * GROUP + sub;
             if (e < nact && look) {
                 const int s = slist ? slist[e] : e;
-                cmask |= coarse[(size_t)s * n + ic].x <= tmax ? (1u << k) : 0u;
+                cmask |= ICPMI_CX(coarse, n, nsplits, s, ic) <= tmax ? (1u << k) : 0u;
             }
         }
         while (__ballot(cmask != 0u)) {
@@ -932,7 +944,7 @@ __device__ __forceinline__ void resolve_certify(const float (&pv)[KEEP > 0 ? KEE
             if (act) {
                 const int e = base + k * GROUP + sub;
                 s = slist ? slist[e] : e;
-                v = coarse[(size_t)s * n + ic];
+                v = make_float2(ICPMI_CX(coarse, n, nsplits, s, ic), ICPMI_CY(coarse, n, nsplits, s, ic));
                 const float tauf = split_tau(px, py, pz, frames[s], bd, sq);
                 whole = v.y <= tauf;                       // a second column is inside the bound
                 slot = !whole && s != bs && v.x <= tauf;
@@ -1039,7 +1051,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
         pv[k] = kBig;
         if (e < nact) {
             const int s = slist ? slist[e] : e;
-            pv[k] = coarse[(size_t)s * n + ic].x;
+            pv[k] = ICPMI_CX(coarse, n, splits, s, ic);
             if (pv[k] < best) {
                 best = pv[k];
                 bs = s;
@@ -1048,7 +1060,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
     }
     for (int e = sub + SUBS * KEEP; e < nact; e += SUBS) {
         const int s = slist ? slist[e] : e;
-        const float v = coarse[(size_t)s * n + ic].x;
+        const float v = ICPMI_CX(coarse, n, splits, s, ic);
         if (v < best) {
             best = v;
             bs = s;
@@ -1105,9 +1117,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
         }
     }
 
+    // The matched target and its normal are gathered for the phase-2 winner NOW, so that the round
+    // trip runs under the certificate; the certificate changes the winner for a few queries in a
+    // thousand, and those gather again.
+    const bool owner = partials && sub == 0 && valid;
+    const int jspec = (unsigned)bj < (unsigned)m ? bj : 0;
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0;
+    if (owner) {
+        q0 = tgt_orig[3 * jspec], q1 = tgt_orig[3 * jspec + 1], q2 = tgt_orig[3 * jspec + 2];
+        n0 = nrm[3 * jspec], n1 = nrm[3 * jspec + 1], n2 = nrm[3 * jspec + 2];
+    }
+
     // phase 3: certificate (resolve_certify)
     unsigned extra_slots = 0, extra_splits = 0;
-    resolve_certify<SUBS, Q, KEEP>(pv, lane, sub, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
+    resolve_certify<SUBS, Q, KEEP>(pv, lane, sub, valid, ic, n, px, py, pz, coarse, splits, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                              bd, bj, extra_slots, extra_splits);
     if (valid && sub == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
@@ -1136,8 +1159,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
             double J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, b = 0.0;
             if (valid) {
                 const int j = (unsigned)bj < (unsigned)m ? bj : 0;
-                const double q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
-                const double n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
+                if (j != jspec) { // the certificate found a nearer target
+                    q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
+                    n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
+                }
                 J[0] = py * n2 - pz * n1; // p x n, icp.hpp:105
                 J[1] = pz * n0 - px * n2;
                 J[2] = px * n1 - py * n0;
@@ -1222,7 +1247,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
         pv[k] = kBig;
         if (e < nact) {
             const int s = slist ? slist[e] : e;
-            pv[k] = coarse[(size_t)s * n + ic].x;
+            pv[k] = ICPMI_CX(coarse, n, splits, s, ic);
             if (pv[k] < best || (pv[k] == best && s < bs)) {
                 best = pv[k];
                 bs = s;
@@ -1231,7 +1256,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
     }
     for (int e = ql + 16 * KEEP4; e < nact; e += 16) {
         const int s = slist ? slist[e] : e;
-        const float v = coarse[(size_t)s * n + ic].x;
+        const float v = ICPMI_CX(coarse, n, splits, s, ic);
         if (v < best || (v == best && s < bs)) {
             best = v;
             bs = s;
@@ -1275,9 +1300,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
         }
     }
 
+    // speculative gather of the phase-2 winner's target and normal (see k_nn_resolve)
+    const bool owner = partials && ql == 0 && valid;
+    const int jspec = (unsigned)bj < (unsigned)m ? bj : 0;
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0;
+    if (owner) {
+        q0 = tgt_orig[3 * jspec], q1 = tgt_orig[3 * jspec + 1], q2 = tgt_orig[3 * jspec + 2];
+        n0 = nrm[3 * jspec], n1 = nrm[3 * jspec + 1], n2 = nrm[3 * jspec + 2];
+    }
+
     // phase 3: certificate (resolve_certify)
     unsigned extra_slots = 0, extra_splits = 0;
-    resolve_certify<16, 4, KEEP4>(pv, lane, ql, valid, ic, n, px, py, pz, coarse, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
+    resolve_certify<16, 4, KEEP4>(pv, lane, ql, valid, ic, n, px, py, pz, coarse, splits, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                         bd, bj, extra_slots, extra_splits);
     if (valid && ql == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
@@ -1306,8 +1340,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
             for (int e = 0; e < 28; ++e) acc[e] = 0.0;
             if (valid) {
                 const int j = (unsigned)bj < (unsigned)m ? bj : 0;
-                const double q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
-                const double n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
+                if (j != jspec) { // the certificate found a nearer target
+                    q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
+                    n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
+                }
                 double J[6];
                 J[0] = py * n2 - pz * n1; // p x n, icp.hpp:105
                 J[1] = pz * n0 - px * n2;
