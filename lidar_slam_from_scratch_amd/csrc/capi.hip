@@ -470,13 +470,13 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
     if (by_sorted_row && (!mfma || qsep)) return fail(ctx, ICPMI_ERR_ARG, "sorted-row lists need the MFMA engine's sorted target");
     if (mfma) {
         const int splits = ctx->nn_splits, nslots = splits * kCols;
-        // bound the slot-minimum buffer (4 B x nslots per row) by chunking the rows: ~1 GiB, or
+        // bound the slot-minimum buffer (2 B x nslots per row) by chunking the rows: ~1 GiB, or
         // ~4 GiB when culling leaves most of it untouched (the pruned engine writes only the
         // listed splits of a row, the layout stays dense)
         const long budget = by_sorted_row ? (4l << 30) : (1l << 30);
-        long chunk = (budget / ((long)nslots * 4)) / kCoarseQueries * kCoarseQueries;
+        long chunk = (budget / ((long)nslots * 2)) / kCoarseQueries * kCoarseQueries; // 2 bytes per slot minimum (bf16)
         chunk = std::max<long>(kCoarseQueries, std::min<long>(chunk, ((long)rows + kCoarseQueries - 1) / kCoarseQueries * kCoarseQueries));
-        if ((rc = reserve(ctx, ctx->slotmin, sizeof(float) * (size_t)chunk * nslots))) return rc;
+        if ((rc = reserve(ctx, ctx->slotmin, sizeof(unsigned short) * (size_t)chunk * nslots))) return rc;
         if ((rc = reserve(ctx, ctx->fb_list, sizeof(int) * ((size_t)rows + 16)))) return rc;
         int *fb_count = (int *)ctx->fb_list.p, *fb_list = fb_count + 16;
         HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, sizeof(int), s));

@@ -360,6 +360,12 @@ __device__ __forceinline__ float min_raw(float a, float b)
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ float max_raw(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float med3_raw(float a, float b, float c)
 {
     float r;
@@ -373,7 +379,7 @@ __device__ __forceinline__ float tag_low5(float x, unsigned tag)
 }
 
 // MODE 0: 1-NN epilogue -> coarse[split][n] = (tagged min, second min over the 32 columns)
-// MODE 1: k-NN epilogue  -> slotmin[query][split*32 + column], every column minimum kept
+// MODE 1: k-NN epilogue  -> slotmin[query][split*32 + column], every column minimum kept (bf16, rounded down)
 // QT = 32-query tiles per wave (even); WAVES = waves per workgroup.  (Tried and dropped, see
 // scripts/micro/README.md: issuing a tile's min3 one tile behind its MFMAs, keeping the next B chunk
 // in flight in registers, QT = 4: none beat this form, all cost occupancy.)
@@ -498,11 +504,21 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
         const int iq = q0 + t * 32 + ql;
         if (MODE == 1) {
             if (iq < n) {
-                float4 *dst = reinterpret_cast<float4 *>(slotmin + (size_t)iq * (nsplits * kCols) + s * kCols + half * 16);
+                // stored as bf16 ROUNDED DOWN (the upper half of the fp32 word of a non-negative value):
+                // half the bytes of the one buffer that grows with rows x slots; a stored minimum never
+                // exceeds the true one, so every "<= bound" test on it stays a superset (k_knn_resolve
+                // inflates the one place that needs an upper bound).  A far-away or NaN row's +Inf / NaN
+                // become kBig, tiny negative values (coincident points) zero.
+                unsigned w[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) // (never above kBig, never NaN: see the 1-NN branch)
-                    dst[e] = make_float4(min_raw(v[4 * e] + pnq, kBig), min_raw(v[4 * e + 1] + pnq, kBig),
-                                         min_raw(v[4 * e + 2] + pnq, kBig), min_raw(v[4 * e + 3] + pnq, kBig));
+                for (int e = 0; e < 8; ++e) {
+                    const float a = max_raw(min_raw(v[2 * e] + pnq, kBig), 0.f), b = max_raw(min_raw(v[2 * e + 1] + pnq, kBig), 0.f);
+                    w[e] = (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xFFFF0000u);
+                }
+                uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(slotmin) +
+                                                       (size_t)iq * (nsplits * kCols) + s * kCols + half * 16);
+                dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+                dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
             }
         } else {
             // top-2 of this lane's 16 columns on the tagged contraction values (3 VALU per value:
@@ -1401,9 +1417,10 @@ constexpr int kKnnBatch = ICPMI_KNN_BATCH; // flagged slots scanned per round (t
 constexpr int kKnnFlagCap = 192;    // slots listed for scanning per row and attempt (a sane bound flags ~10)
 constexpr int kKnnMaxSplits = 256;  // per-split bounds cached in LDS (512k targets); beyond: recomputed
 #ifndef ICPMI_KNN_REGSLOTS
-#define ICPMI_KNN_REGSLOTS 26 /* 26 -> 119 VGPRs = 4 waves per SIMD; 32 -> 129 = 3 waves: 430 vs 529 us on C3 */
+#define ICPMI_KNN_REGSLOTS 26 /* as fp32: 26 -> 119 VGPRs = 4 waves per SIMD, 32 -> 129 = 3 waves (430 vs 529 us on C3);
+                                 as bf16 pairs 107 / 115 VGPRs, 382 / 395 us: 26 kept */
 #endif
-constexpr int kKnnRegSlots = ICPMI_KNN_REGSLOTS;    // slot minima per lane kept in registers (1664 slots = 106k targets)
+constexpr int kKnnRegSlots = ICPMI_KNN_REGSLOTS;    // slot minima per lane kept in registers, two per dword (1664 slots = 106k targets)
 
 // Ascending bitonic sort of one value per lane (21 compare-exchange steps); lane i ends up
 // with the i-th smallest.  Used for "k-th smallest of 64": a rank-by-counting loop costs 64
@@ -1468,32 +1485,46 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     auto gsplit = [&](int sp) -> int { return LISTED ? (sp < kKnnMaxSplits ? s_list[sp] : slist[sp]) : sp; };
     auto gslot = [&](int e) -> int { return LISTED ? gsplit(e / kCols) * kCols + (e % kCols) : e; };
     const int nloc = LISTED ? nact * kCols : nslots; // slots this row looks at
-    const float *mine = slotmin + (size_t)local * nslots;
+    const unsigned short *mine16 = reinterpret_cast<const unsigned short *>(slotmin) + (size_t)local * nslots;
+    auto mine = [&](int g) -> float { return __uint_as_float((unsigned)mine16[g] << 16); }; // bf16, rounded down
     const int kk = k < 64 ? k : 64;
     const double kInf = 1.7976931348623157e308;
 
     // per-lane minimum of the slot minima, with its slot.  The first kKnnRegSlots values per
     // lane stay in registers for the flagging pass below (the slot minima are the bulk of this
     // kernel's HBM traffic: read them once).
-    float sv[kKnnRegSlots];
-    float lmin = kBig;
-    int lslot = lane < nloc ? lane : 0; // LOCAL slot number
+    // (kept and compared as the raw 16-bit patterns: non-negative bf16 values order like unsigned
+    // integers; a lane owns PAIRS of neighbouring slots, 2 * lane + 128 u + {0, 1}, so that it loads
+    // whole dwords -- 2-byte loads came out of the compiler serialised through one register)
+    constexpr int kPairs = kKnnRegSlots / 2;
+    static_assert(kKnnRegSlots % 2 == 0 && kKnnRegSlots <= 32, "pairs of slots, one flag bit each");
+    unsigned sv[kPairs];
+    unsigned lmin16 = 0x7F61u; // kBig as stored
+    int lslot = 2 * lane < nloc ? 2 * lane : 0; // LOCAL slot number
 #pragma unroll
-    for (int u = 0; u < kKnnRegSlots; ++u) {
-        const int e = lane + 64 * u;
-        sv[u] = e < nloc ? mine[gslot(e)] : kBig;
-        if (sv[u] < lmin) {
-            lmin = sv[u];
+    for (int u = 0; u < kPairs; ++u) {
+        const int e = 2 * lane + 128 * u;
+        sv[u] = e < nloc ? *reinterpret_cast<const unsigned *>(mine16 + gslot(e)) : 0x7F617F61u;
+    }
+#pragma unroll
+    for (int u = 0; u < kPairs; ++u) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned v = h ? sv[u] >> 16 : sv[u] & 0xFFFFu;
+            if (v < lmin16) {
+                lmin16 = v;
+                lslot = 2 * lane + 128 * u + h;
+            }
+        }
+    }
+    for (int e = 128 * kPairs + lane; e < nloc; e += 64) {
+        const unsigned v = mine16[gslot(e)];
+        if (v < lmin16) {
+            lmin16 = v;
             lslot = e;
         }
     }
-    for (int e = lane + 64 * kKnnRegSlots; e < nloc; e += 64) {
-        const float v = mine[gslot(e)];
-        if (v < lmin) {
-            lmin = v;
-            lslot = e;
-        }
-    }
+    const float lmin = __uint_as_float(lmin16 << 16);
     // best slot: lane with the smallest minimum (ties: lowest lane)
     int bslot;
     {
@@ -1579,9 +1610,10 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         const double u = 5.9604644775390625e-08;
         const double eps = kReprEps * a * (1.0 + 1e-6);
         const double A = kArithBound * u * a * a;
-        const double ts = tS > 0.f ? (double)tS * (1.0 + 1e-6) : 0.0;
+        // (the stored minima are bf16 rounded down: the true one is within 2^-7 above)
+        const double ts = tS > 0.f ? (double)tS * (1.0 + 0.0078125 + 1e-4) : 0.0;
         const double xr = eps + sqrt(eps * eps + (ts + eps * eps + A)); // sqrt(dmax)
-        const double dmax = tS >= kBig ? 1.0e300 : xr * xr * (1.0 + 1e-9);
+        const double dmax = tS >= 2.9e38f ? 1.0e300 : xr * xr * (1.0 + 1e-9); // (kBig as stored: bf16, rounded down)
         T = T < dmax ? T : dmax; // (NaN rows: T becomes dmax)
     }
 
@@ -1617,12 +1649,16 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         // LISTED (compacted through LDS); every lane hands over one survivor per round, so the
         // rounds number what the busiest lane holds (one to three), not the slots per lane.
         const float tall = T >= 1.0e299 ? 3.4028235e38f : all_splits_tau(px, py, pz, *gframe, T, sq);
+        const unsigned tall16 = __float_as_uint(tall) >> 16; // a stored (bf16) value is <= tall iff its pattern is <= this one
         unsigned regflags = 0u;
 #pragma unroll
-        for (int u = 0; u < kKnnRegSlots; ++u) {
-            const int e = lane + 64 * u;
-            regflags |= (e < nloc && e != bslot && sv[u] <= tall) ? (1u << u) : 0u;
-        }
+        for (int u = 0; u < kPairs; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * lane + 128 * u + h;
+                const unsigned v = h ? sv[u] >> 16 : sv[u] & 0xFFFFu;
+                regflags |= (e < nloc && e != bslot && v <= tall16) ? (1u << (2 * u + h)) : 0u;
+            }
         int nf = 0;
         auto list_flagged = [&](bool cand, int e) { // wave-uniform call; `cand` lanes test slot e against its split
             bool flag = false;
@@ -1630,7 +1666,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
                 const int sp = e / kCols;
                 const float tauf = sp < kKnnMaxSplits ? tau_sp[wave][sp]
                                                       : (T >= 1.0e299 ? kBig : split_tau(px, py, pz, frames[gsplit(sp)], T, sq));
-                flag = mine[gslot(e)] <= tauf;
+                flag = mine(gslot(e)) <= tauf;
             }
             const unsigned long long fm = __ballot(flag);
             if (flag) {
@@ -1643,12 +1679,12 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             const bool act = regflags != 0u;
             const int u = act ? __ffs((int)regflags) - 1 : 0;
             regflags &= regflags - 1u; // (0 stays 0)
-            list_flagged(act, lane + 64 * u);
+            list_flagged(act, 2 * lane + 128 * (u >> 1) + (u & 1));
         }
 #pragma unroll 1
-        for (int e0 = 64 * kKnnRegSlots; e0 < nloc; e0 += 64) { // slots beyond the register-resident ones (> 131k targets)
+        for (int e0 = 128 * kPairs; e0 < nloc; e0 += 64) { // slots beyond the register-resident ones (> 106k targets)
             const int e = e0 + lane;
-            const bool cand = e < nloc && e != bslot && mine[gslot(e)] <= tall;
+            const bool cand = e < nloc && e != bslot && mine(gslot(e)) <= tall;
             if (__ballot(cand)) list_flagged(cand, e);
         }
         const bool overflow = nf > kKnnFlagCap; // (only with a bound that rules nothing out)
