@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Copy the summaries of gpurun_out/final (scripts/final_profile.sh) into profiles/<round>/.
+gpurun merges into gpurun_out/, so older runs' files may lie beside the new ones: the newest of
+each kind is taken.  usage: python scripts/collect_profiles.py r2_final"""
+import glob, json, os, re, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = os.path.join(ROOT, "gpurun_out", "final")
+P = os.path.join(ROOT, "profiles", sys.argv[1])
+os.makedirs(os.path.join(P, "small"), exist_ok=True)
+
+def newest(pattern):
+    c = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    assert c, pattern
+    return c[-1]
+
+for f in ("bench.json", "bench_20.json", "bench_extra.json", "engines_100k.json", "engines_1m.json", "engines_lidar_raw.json",
+          "event_overhead.txt", "sequence_200.json", "summary.txt", "ab_r1_r2.json", "threshold_sweep.json"):
+    if os.path.exists(os.path.join(F, f)):
+        shutil.copy(os.path.join(F, f), os.path.join(P, f))
+shutil.copy(newest(F + "/stats/**/*kernel_stats.csv"), P + "/kernel_stats.csv")
+for g in ("fetch_size", "write_size", "grbm_gui_active", "sq_insts_valu", "sq_waves"):
+    shutil.copy(newest(F + "/pmc_%s/**/*counter_collection.csv" % g), P + "/pmc_%s.csv" % g)
+shutil.copy(newest(F + "/small/stats/**/*kernel_stats.csv"), P + "/small/kernel_stats.csv")
+for f in ("sequence_40.json", "sequence_40_under_rocprof.json"):
+    shutil.copy(os.path.join(F, "small", f), os.path.join(P, "small", f))
+t = open(os.path.join(F, "shard_overhead.json")).read()
+open(os.path.join(P, "shard_overhead.json"), "w").write(t[t.index("{"):])      # (RCCL prints its banner on stdout)
+s = open(os.path.join(P, "summary.txt")).read()
+open(os.path.join(P, "summary.txt"), "w").write(re.sub(r"/tmp/code/[^ ]*/repo/", "", s))
+d = json.load(open(os.path.join(P, "bench.json")))
+print("bench30", round(d["value"], 1), round(d["steady_state_it_per_s"], 1), d["roofline"]["avg_launch_ms"], round(d["roofline"]["frac"], 4),
+      d["roofline"]["traffic"], round(d["speedup_vs_cpu_1thread"], 1), round(d["cpu_baseline"]["value"], 2))
+print(d["stage_ms_untimed_call"]); print(d["parity"]); print("pruned", d["pruned_engine_extra"]["value"], d["resolve_counters"])
+print("bench20", json.load(open(os.path.join(P, "bench_20.json")))["value"])
+print({k: v["loop_us_per_pass"] for k, v in json.loads(t[t.index("{"):]).items()})
+q = json.load(open(os.path.join(P, "sequence_200.json")))
+print({k: q[k] for k in ("gpu_ms_per_frame_file_to_pose", "gpu_frame_ms_median", "gpu_frame_ms_p95", "iterations_total", "gated_frames")}, q["oracle"])
+q = json.load(open(os.path.join(P, "small", "sequence_40.json")))
+print({k: q[k] for k in ("gpu_ms_per_frame_file_to_pose", "gpu_frame_ms_median", "iterations_total")})
+print(json.dumps(json.load(open(os.path.join(P, "ab_r1_r2.json")))))
+print(json.dumps(json.load(open(os.path.join(P, "bench_extra.json"))))[:1400])
