@@ -228,6 +228,12 @@ int icpmi_stream_push(icpmi_ctx *ctx, const double *d_raw_xyz, int64_t n_raw, do
 int icpmi_stream_push_host(icpmi_ctx *ctx, const double *raw_xyz, int64_t n_raw, double voxel_size,
                            int64_t min_points, const icpmi_config *cfg, icpmi_result *result,
                            double *error_history, int32_t history_cap, icpmi_stream_info *info);
+/* Same with the raw scan in a file (load_ply / load_bin, file_utils.cpp:20-141, what slam_node.cpp:121
+ * reads): a KITTI ".bin" goes from disk through pinned memory to the device as float32 and
+ * everything behind the read is queued without a wait in between; a PLY takes the host parser. */
+int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, int64_t min_points,
+                           const icpmi_config *cfg, icpmi_result *result, double *error_history,
+                           int32_t history_cap, icpmi_stream_info *info);
 int icpmi_stream_reset(icpmi_ctx *ctx);   /* forget the resident frame (a new sequence starts) */
 
 /* Replaces ScanContext::compute (core/scan_context.hpp:44-82): 20 rings x 60 sectors max-height

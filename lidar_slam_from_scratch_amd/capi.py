@@ -24,7 +24,7 @@ EXPORTS = [
     "icpmi_comm_init_callbacks", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
     "icpmi_scan_context", "icpmi_scan_context_distances", "icpmi_load_cloud", "icpmi_load_cloud_device",
     "icpmi_upload_points_f32", "icpmi_discover_frames", "icpmi_estimate_normals_rows",
-    "icpmi_stream_push", "icpmi_stream_push_host", "icpmi_stream_reset",
+    "icpmi_stream_push", "icpmi_stream_push_host", "icpmi_stream_push_file", "icpmi_stream_reset",
     "icpmi_reset_profile", "icpmi_get_profile",
 ]
 
@@ -160,6 +160,8 @@ def load_library(path=None):
     L.icpmi_stream_push.argtypes = [vp, vp, C.c_int64, C.c_double, C.c_int64, C.POINTER(Config), C.POINTER(Result), dp,
                                     C.c_int32, C.POINTER(StreamInfo)]
     L.icpmi_stream_push_host.argtypes = [vp, dp, C.c_int64, C.c_double, C.c_int64, C.POINTER(Config), C.POINTER(Result), dp,
+                                         C.c_int32, C.POINTER(StreamInfo)]
+    L.icpmi_stream_push_file.argtypes = [vp, C.c_char_p, C.c_double, C.c_int64, C.POINTER(Config), C.POINTER(Result), dp,
                                          C.c_int32, C.POINTER(StreamInfo)]
     L.icpmi_stream_reset.argtypes = [vp]
     L.icpmi_scan_context.argtypes = [vp, dp, C.c_int64, dp]
@@ -368,6 +370,15 @@ class Context:
         hist = np.zeros(max(cap, 1))
         res, info = Result(), StreamInfo()
         self._check(self._lib.icpmi_stream_push_host(self._h, _dp(pts), pts.shape[0], float(voxel), int(min_points),
+                                                     C.byref(cfg), C.byref(res), _dp(hist), cap, C.byref(info)))
+        return res, hist[:res.history_len].copy(), info
+
+    def stream_push_file(self, path, voxel, min_points, cfg):
+        """stream_push with the raw scan in a file (.bin: disk -> pinned memory -> device as float32)"""
+        cap = cfg.max_iterations + 1
+        hist = np.zeros(max(cap, 1))
+        res, info = Result(), StreamInfo()
+        self._check(self._lib.icpmi_stream_push_file(self._h, os.fsencode(path), float(voxel), int(min_points),
                                                      C.byref(cfg), C.byref(res), _dp(hist), cap, C.byref(info)))
         return res, hist[:res.history_len].copy(), info
 

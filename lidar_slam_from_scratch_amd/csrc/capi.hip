@@ -128,6 +128,10 @@ struct icpmi_ctx {
     int nn_ms = 0;                            // component stride of the SoA sorted target
     IcpState *d_state = nullptr;   // two of them (align_device alternates in the sharded loop)
     IcpState *h_state = nullptr;   // pinned
+    double *h_hist = nullptr;      // pinned: the error history of the last call
+    size_t h_hist_cap = 0;
+    void *h_file = nullptr;        // pinned: a frame file on its way to the device (icpmi_stream_push_file)
+    size_t h_file_cap = 0;
     int32_t *h_flags = nullptr;    // host-mapped ring: (iteration + 1) * 2 + done, written by the device
     int32_t *d_flags = nullptr;    // the same words through the device's address space
 
@@ -831,13 +835,22 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     delete t_total;
     t_total = nullptr;
 
+    // state and history come back behind ONE wait (the history through the pinned staging area: a
+    // second, blocking copy after the wait was one more host round trip per call)
+    const int hcopy = std::min(max_hist, history_cap);
+    if ((int)ctx->h_hist_cap < hcopy) {
+        if (ctx->h_hist) (void)hipHostFree(ctx->h_hist);
+        ctx->h_hist = nullptr;
+        ctx->h_hist_cap = 0;
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_hist, sizeof(double) * (size_t)(hcopy + 64), hipHostMallocDefault));
+        ctx->h_hist_cap = (size_t)hcopy + 64;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(hs, st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+    if (hcopy > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist, hist, sizeof(double) * (size_t)hcopy, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     HIP_TRY(ctx, hipGetLastError());
     const int hl = std::min(hs->hist_len, max_hist);
-    if (hl > 0)
-        HIP_TRY(ctx, hipMemcpy(error_history, hist, sizeof(double) * (size_t)std::min(hl, history_cap),
-                               hipMemcpyDeviceToHost));
+    if (hl > 0) memcpy(error_history, ctx->h_hist, sizeof(double) * (size_t)std::min(hl, history_cap));
     harvest_profile(ctx);
     if (hs->error)
         return fail(ctx, ICPMI_ERR_RCCL, "the ranks of this sharded run disagreed on the end of the loop "
@@ -1018,6 +1031,8 @@ void icpmi_destroy(icpmi_ctx *ctx)
         release(*b);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+    if (ctx->h_hist) (void)hipHostFree(ctx->h_hist);
+    if (ctx->h_file) (void)hipHostFree(ctx->h_file);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     for (EventPair &p : ctx->ev_pool) {
         (void)hipEventDestroy(p.a);
@@ -1553,6 +1568,54 @@ int icpmi_stream_push(icpmi_ctx *ctx, const double *d_raw_xyz, int64_t n_raw, do
     std::swap(ctx->stream_prev, ctx->stream_cur);         // prev_points_ = curr (slam_node.cpp:128,152), no copy
     ctx->stream_prev_n = n_cur;
     return ICPMI_OK;
+}
+
+int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, int64_t min_points, const icpmi_config *cfg,
+                           icpmi_result *result, double *error_history, int32_t history_cap, icpmi_stream_info *info)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!path) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    const size_t len = strlen(path);
+    if (!(len >= 4 && strcmp(path + len - 4, ".bin") == 0)) {
+        // PLY: host parser (header rules, ASCII numbers), then the host-pointer form
+        int64_t n = 0;
+        if ((rc = icpmi_load_cloud(path, nullptr, 0, &n))) return fail(ctx, rc, "%s", icpmi_last_error(nullptr));
+        if (n <= 0) return fail(ctx, ICPMI_ERR_ARG, "no points in %s", path);
+        std::vector<double> host(3 * (size_t)n);
+        if ((rc = icpmi_load_cloud(path, host.data(), n, &n))) return fail(ctx, rc, "%s", icpmi_last_error(nullptr));
+        return icpmi_stream_push_host(ctx, host.data(), n, voxel_size, min_points, cfg, result, error_history, history_cap, info);
+    }
+    // KITTI .bin: the file is read into pinned memory and everything behind it -- copy, widening,
+    // voxel filter, registration -- is queued on the context's stream without a wait in between
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(ctx, ICPMI_ERR_ARG, "Cannot open file: %s", path); // file_utils.cpp:116-118
+    struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
+    fseek(f, 0, SEEK_END);
+    const long size = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    const int64_t n = size / (4 * (long)sizeof(float)); // file_utils.cpp:127
+    if (n <= 0 || n > 700000000) return fail(ctx, ICPMI_ERR_ARG, "%lld points in %s", (long long)n, path);
+    const size_t bytes = 4 * sizeof(float) * (size_t)n;
+    if (ctx->h_file_cap < bytes) {
+        if (ctx->h_file) (void)hipHostFree(ctx->h_file);
+        ctx->h_file = nullptr;
+        ctx->h_file_cap = 0;
+        HIP_TRY(ctx, hipHostMalloc(&ctx->h_file, bytes + bytes / 4, hipHostMallocDefault));
+        ctx->h_file_cap = bytes + bytes / 4;
+    }
+    // (the previous frame's copy out of this buffer finished long ago: every push ends with a stream wait)
+    const size_t got = fread(ctx->h_file, 1, bytes, f);
+    if (got < bytes) memset((char *)ctx->h_file + got, 0, bytes - got); // a short read leaves zeros, like the host loader
+    if ((rc = reserve(ctx, ctx->f32_stage, bytes))) return rc;
+    if ((rc = reserve(ctx, ctx->stage_a, sizeof(double) * 3 * (size_t)n))) return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->f32_stage.p, ctx->h_file, bytes, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)ctx->f32_stage.p, (int)n, 4,
+                       (double *)ctx->stage_a.p);
+    HIP_TRY(ctx, hipGetLastError());
+    return icpmi_stream_push(ctx, (const double *)ctx->stage_a.p, n, voxel_size, min_points, cfg, result, error_history,
+                             history_cap, info);
 }
 
 int icpmi_stream_push_host(icpmi_ctx *ctx, const double *raw_xyz, int64_t n_raw, double voxel_size, int64_t min_points,

@@ -129,26 +129,18 @@ def run_odometry_device(raw_frames, ctx, voxel=0.5, max_iterations=50, tolerance
 
 
 def run_odometry_stream(paths, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6, min_points=1000):
-    """The same loop over frame FILES with everything but the file read on the device: each
-    scan goes from disk to HBM (`.bin`: float32 records, widened there), then one
-    `icpmi_stream_push` per frame does slam_node.cpp:122-152 -- voxel filter, min-points guard,
+    """The same loop over frame FILES with everything but the file read on the device: one
+    `icpmi_stream_push_file` per frame does slam_node.cpp:121-152 -- the scan goes from disk through
+    pinned memory to HBM (`.bin`: float32 records, widened there), voxel filter, min-points guard,
     registration against the previous filtered scan that stayed resident -- and this function
-    applies the reference's gate and pose update (slam_node.cpp:139-142).  torch is used for the
-    raw-scan buffer only."""
-    import torch
+    applies the reference's gate and pose update (slam_node.cpp:139-142).  No torch in here."""
     from . import capi
     track = OdometryTrack()
     cfg = capi.Context.make_config(max_iterations=max_iterations, tolerance=tolerance)
     ctx.stream_reset()
-    raw = None
     for k, path in enumerate(paths):
         t0 = time.perf_counter()
-        n = ctx.load_cloud_device_rows(path)
-        if raw is None or raw.shape[0] < n:
-            raw = torch.empty((max(n, 1) * 5 // 4, 3), dtype=torch.float64, device="cuda")
-            torch.cuda.synchronize()          # the library's stream is not torch's (include/icp_mi355x.h)
-        n = ctx.load_cloud_device(path, raw.data_ptr(), raw.shape[0])
-        res, _hist, info = ctx.stream_push(raw.data_ptr(), n, voxel, min_points, cfg)
+        res, _hist, info = ctx.stream_push_file(path, voxel, min_points, cfg)
         if info.status == capi.STREAM_FIRST_FRAME:
             continue
         if info.status == capi.STREAM_TOO_FEW_POINTS:            # slam_node.cpp:125-130

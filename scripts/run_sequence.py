@@ -6,9 +6,10 @@ KITTI's own .bin format).
     python scripts/run_sequence.py --data_dir /data/kitti/sequences/00/velodyne [--frames 0:200]
     python scripts/run_sequence.py --make-synthetic /tmp/drive --frames 0:200     # writes the .bin files first
 
-What runs: discover_frames (file_utils.cpp:217-247) -> per frame: file -> HBM (float32, widened
-on the device), icpmi_stream_push = voxel filter + min-points guard + point-to-plane ICP against
-the previous filtered scan, which stays resident (slam_node.cpp:122-152) -> the reference's gate
+What runs: discover_frames (file_utils.cpp:217-247) -> per frame icpmi_stream_push_file: file ->
+pinned memory -> HBM (float32, widened on the device), voxel filter + min-points guard +
+point-to-plane ICP against the previous filtered scan, which stays resident
+(slam_node.cpp:121-152) -> the reference's gate
 and pose update (slam_node.cpp:139-142).  With --oracle the same frames also go through the CPU
 oracle loop (test infrastructure) for iteration counts and ATE.  Prints one JSON object.
 A --data_dir that does not exist is skipped with a message and exit code 0 (no dataset ships with

@@ -91,6 +91,17 @@ def test_stream_push_is_process_frame(tmp_path, oracle):
     raw = [capi.load_cloud(p) for p in paths[:8]]
     td = odometry.run_odometry_device(raw, ctx, voxel=0.5)
     assert td.iterations == tr.iterations[:7]
+    # the device-pointer form with the scan loaded by icpmi_load_cloud_device (what round 2's first harness did)
+    ctx.stream_reset()
+    its = []
+    dbuf = torch.empty((max(r.shape[0] for r in raw) + 8, 3), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for p in paths[:8]:
+        n = ctx.load_cloud_device(p, dbuf.data_ptr(), dbuf.shape[0])
+        res, _, info = ctx.stream_push(dbuf.data_ptr(), n, 0.5, 1000, capi.Context.make_config())
+        if info.status == capi.STREAM_REGISTERED:
+            its.append(res.num_iterations)
+    assert its == tr.iterations[:7]
     # ... and through the host-pointer form the Eigen adapter's OdometryStream uses
     ctx.stream_reset()
     its = []
