@@ -26,6 +26,18 @@ out["c2_lidar_pair"] = {"n_src": int(src.shape[0]), "n_tgt": int(tgt.shape[0]), 
                         "cpu_call_ms": 1e3 * c, "iterations": res.num_iterations, "pose_dt": dt, "pose_dr": dr,
                         "iters_equal": res.num_iterations == ref.num_iterations}
 
+# the same pair at the size configs[1] names (~20k points: the stand-in at a 0.3 m voxel)
+src, tgt, T = synth.c2_lidar_pair(voxel=0.3)
+ctx.align(src, tgt, cfg)
+t0 = time.perf_counter(); res, hist = ctx.align(src, tgt, cfg); g = time.perf_counter() - t0
+t0 = time.perf_counter(); ref = orc.icp_point_to_plane(src, tgt); c = time.perf_counter() - t0
+dt, dr = synth.pose_delta(np.array(res.transformation[:]).reshape(4, 4), ref.transformation)
+pctx.align(src, tgt, cfg)
+t0 = time.perf_counter(); pres, _ = pctx.align(src, tgt, cfg); gp = time.perf_counter() - t0
+out["c2_lidar_pair_20k"] = {"n_src": int(src.shape[0]), "n_tgt": int(tgt.shape[0]), "gpu_call_ms": 1e3 * g,
+                            "gpu_call_ms_pruned_engine": 1e3 * gp, "cpu_call_ms": 1e3 * c, "iterations": res.num_iterations,
+                            "pose_dt": dt, "pose_dr": dr, "iters_equal": res.num_iterations == ref.num_iterations}
+
 # C5 stand-in: 12-frame synthetic drive, frame-to-frame odometry
 frames = [synth.lidar_frame(f) for f in range(12)]
 truth = [synth.lidar_pose(f) for f in range(12)]

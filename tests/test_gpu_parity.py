@@ -609,6 +609,24 @@ def test_ring_neighbourhood_normals_bit_exact(gpu_ctx, oracle):
     np.testing.assert_allclose(hist, ref.error_history, rtol=0, atol=1e-9)
 
 
+def test_c2_pair_at_kitti_size(gpu_ctx, oracle):
+    """BASELINE.json configs[1] names ~20k points after the 0.5 m voxel filter (KITTI); the synthetic
+    stand-in reaches that size at a 0.3 m voxel (17.9k -> 20.4k points).  Reference defaults
+    (50 iterations, 1e-6, slam_node.cpp:134-136) against a live oracle run: same iteration count
+    and flag, pose within the north_star's 1e-4 m / 1e-4 rad, history within 1e-9."""
+    src, tgt, _ = synth.c2_lidar_pair(voxel=0.3)
+    assert 17000 < src.shape[0] < 19000 and 19500 < tgt.shape[0] < 21500
+    res, hist = gpu_ctx.align(src, tgt, capi.Context.make_config())
+    ref = oracle.icp_point_to_plane(src, tgt, nthreads=8)
+    assert res.num_iterations == ref.num_iterations and bool(res.converged) == ref.converged
+    dt, dr = synth.pose_delta(np.array(res.transformation[:]).reshape(4, 4), ref.transformation)
+    assert dt <= 1e-4 and dr <= 1e-4
+    np.testing.assert_allclose(hist, ref.error_history, rtol=0, atol=1e-9)
+    idx, d2 = gpu_ctx.nearest_batch(tgt, src)
+    oidx, od2 = oracle.KDTree(tgt).nearest_batch(src, nthreads=8)
+    assert (idx == oidx).all() and (d2 == od2).all()
+
+
 def test_nonfinite_targets_are_never_neighbours(gpu_ctx, oracle):
     """A target with an Inf or NaN coordinate has no finite distance to anything, so no
     `dist_sq < best` (kdtree.hpp:125) ever selects it: every engine must return the nearest of
