@@ -46,7 +46,7 @@
 //     contraction BEFORE the rest of |P|^2 is added; the contraction already holds the leading
 //     piece of |P|^2, so it is within 2^-7 a^2 of the squared distance d: the tag moves it by
 //     < 2^-19 (d + 2^-7 a^2) = 2^-19 d + u a^2 / 4; the sum is truncated and tagged again, another
-//     2^-19 d (both relative parts are the 4e-6 inflation of tau).
+//     2^-19 d (both relative parts, 3.8e-6 together, are inside the 5e-6 inflation of tau).
 //   52 u a^2 is used.
 //
 // Engine 3 (ICPMI_SEARCH_MFMA_PRUNED, opt-in) runs the same coarse unit and the same resolve on
@@ -824,7 +824,7 @@ __device__ __forceinline__ float tau_from_a(double a, double d, double sqrt_d)
     const double u = 5.9604644775390625e-08; // 2^-24
     const double eps = kReprEps * a * (1.0 + 1e-6);
     double tau = d + eps * (2.0 * sqrt_d + eps) + kArithBound * u * a * a;
-    tau = tau * (1.0 + 4e-6) + 1e-300; // column tag (2^-20) + slack for this fp64 evaluation
+    tau = tau * (1.0 + 5e-6) + 1e-300; // the two column tags (2 x 2^-19 relative) + slack for this fp64 evaluation
     if (!(tau < 3.0e38)) return 3.4028235e38f; // beyond fp32 (or NaN): every recorded value is inside the bound
     return __uint_as_float(__float_as_uint((float)tau) + 1u); // round up (tau > 0)
 }
