@@ -123,6 +123,23 @@ def test_stream_push_is_process_frame(tmp_path, oracle):
     assert (i0.status, i1.status, i2.status) == (capi.STREAM_FIRST_FRAME, capi.STREAM_TOO_FEW_POINTS, capi.STREAM_REGISTERED)
     assert i1.n_filtered < 1000 and i2.n_target == i1.n_filtered and not r1.converged and len(h1) == 0
     assert list(r1.transformation) == list(np.eye(4).reshape(16))
+    # frames as binary PLY (what the node really loads, slam_node.cpp:121): the host parser feeds the same stream
+    ctx.stream_reset()
+    its = []
+    for k in range(3):
+        rec = np.zeros((raw[k].shape[0], 4), dtype=np.float32)
+        rec[:, :3] = raw[k]
+        ply = tmp_path / ("%06d.ply" % k)
+        with open(ply, "wb") as f:
+            f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\n"
+                     "property float z\nproperty float intensity\nend_header\n" % rec.shape[0]).encode())
+            f.write(rec.tobytes())
+        res, _, info = ctx.stream_push_file(str(ply), 0.5, 1000, cfg)
+        if info.status == capi.STREAM_REGISTERED:
+            its.append(res.num_iterations)
+    assert its == tr.iterations[:2]
+    with pytest.raises(capi.IcpError):
+        ctx.stream_push_file(str(tmp_path / "missing.bin"), 0.5, 1000, cfg)
     want = oracle.icp_point_to_plane(oracle.voxel_downsample(raw[2], 0.5), oracle.voxel_downsample(few, 0.5))
     assert r2.num_iterations == want.num_iterations and abs(r2.final_error - want.final_error) < 1e-9
     ctx.close()
