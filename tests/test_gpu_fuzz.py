@@ -1,0 +1,17 @@
+"""Randomised cross-check of all four search engines, the k-NN lists and the normals against the
+oracle's brute force (scripts/fuzz_engines.py): 150 seeded trials here; 4,000 were run once
+(DESIGN.md section 2)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+def test_fuzz_engines_against_brute_force(oracle, monkeypatch):
+    import fuzz_engines
+    monkeypatch.setattr(sys, "argv", ["fuzz_engines.py", "150", "20260"])
+    assert fuzz_engines.main() == 0
