@@ -82,6 +82,39 @@ def main():
                     if not (got == want).all():
                         bad += 1
                         print("MISMATCH normals seed %d engine %s kind %s n_t %d: %d rows differ" % (seed, name, tkind, n_t, int((got != want).any(axis=1).sum())))
+        # voxel filter: centroids bit-identical to the oracle's (sums in input order)
+        if finite_t and n_t >= 1:
+            vox = float(rng.choice([0.05, 0.2, 0.5])) * scale
+            ext = np.abs(tgt - tgt.min(axis=0)).max() / vox
+            if ext < 1.5e6:
+                gv, ov = ctxs["auto"].voxel_downsample(tgt, vox), orc.voxel_downsample(tgt, vox)
+                if gv.shape != ov.shape or not (gv == ov).all():
+                    bad += 1
+                    print("MISMATCH voxel seed %d n_t %d voxel %g" % (seed, n_t, vox))
+        # a short registration on well-conditioned geometry: same error history as the oracle loop
+        if finite_t and tkind in ("uniform", "clusters", "mixed") and n_t >= 300 and abs(offset).max() <= 1e3:
+            from lidar_slam_from_scratch_amd import synth
+            # a small motion about the cloud's own centre (one about a far-away origin throws the cloud
+            # out of the basin of convergence, and a diverging ICP amplifies the last bit of every sum)
+            T = synth.make_transform(rng.normal(0, 0.003, 3), rng.normal(0, 0.005, 3) * scale)
+            c = tgt.mean(axis=0)
+            src = np.ascontiguousarray((tgt[rng.permutation(n_t)[: max(64, n_t // 2)]] - c - T[:3, 3]) @ T[:3, :3] + c)
+            ref = orc.icp_point_to_plane(src, tgt, 4, 0.0, 0.0, nthreads=8)
+            for name in ("auto", "mfma", "pruned"):
+                res, hist = ctxs[name].align(src, tgt, capi.Context.make_config(4, 0.0, 0.0))
+                h = np.asarray(ref.error_history)
+                if h[-1] > 2.0 * h[0] or (np.diff(h[1:]) > 0).any():
+                    continue   # (diverged or erratic: every rounding difference is amplified step by step)
+                # (clustered clouds give normal equations with condition numbers of 1e8 and more: the order of
+                # the 28 sums then shows at 1e-6 relative in the history -- the first entry, which no solve
+                # precedes, agrees to the last digit; the north_star's tolerance on the pose is 1e-4.  The source
+                # is an exact subset of the target here, so the loop converges to rounding level: entries
+                # under 1e-6 of the cloud's size are noise on both sides)
+                dt, dr = synth.pose_delta(np.array(res.transformation[:]).reshape(4, 4), ref.transformation)
+                if (res.num_iterations != ref.num_iterations or abs(hist[0] - ref.error_history[0]) > 1e-12 * max(1.0, scale)
+                        or not np.allclose(hist, ref.error_history, rtol=1e-4, atol=1e-6 * scale) or dt > 1e-4 * scale or dr > 1e-4):
+                    bad += 1
+                    print("MISMATCH align seed %d engine %s kind %s n_t %d: %s vs %s" % (seed, name, tkind, n_t, hist, ref.error_history))
         if (t + 1) % 20 == 0:
             print("%d trials, %d mismatches, %.0f s" % (t + 1, bad, time.time() - t0), flush=True)
     print("fuzz: %d trials, %d mismatches" % (trials, bad))
