@@ -63,16 +63,16 @@ struct EventPair {
 enum Stage { ST_NN = 0, ST_REDUCE = 1, ST_TRANSFORM = 2, ST_NORMALS = 3, ST_TOTAL = 4, ST_LOOP = 5, ST_SETUP = 6, ST_COARSE = 7 };
 
 // roctx ranges around the stages of a call (SURVEY section 5 "Tracing"): visible to
-// `rocprofv3 --marker-trace`.  The library is looked up at run time -- libroctx64 is whichever
-// copy the process already has (torch bundles one) or the ROCm one -- and a missing one only
-// means no ranges.  Costs two indirect calls per stage when nothing listens.
+// `rocprofv3 --marker-trace`.  The library is looked up at run time (the rocprofiler-sdk's roctx
+// first, the older libroctx64 otherwise) and a missing one only means no ranges.  Costs two indirect calls per stage when nothing listens.
 struct Roctx {
     int (*push)(const char *) = nullptr;
     int (*pop)() = nullptr;
     Roctx()
     {
-        const char *names[] = {"libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so.4",
-                               "librocprofiler-sdk-roctx.so.1"};
+        // rocprofv3 traces the rocprofiler-sdk's roctx; the older libroctx64 is what roctracer-era tools see
+        const char *names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1",
+                               "libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so.4"};
         for (const char *nm : names) {
             void *lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
             if (!lib) continue;
