@@ -11,3 +11,6 @@ for flags in "$@"; do
     echo "=== $flags"
     python scripts/prof_summary.py "gpurun_out/sweep_$tag" | head -8
 done
+# leave the default build behind
+rm -f lidar_slam_from_scratch_amd/csrc/capi.o
+make -s -C lidar_slam_from_scratch_amd/csrc > /dev/null 2>&1
