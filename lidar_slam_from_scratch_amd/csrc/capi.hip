@@ -290,6 +290,29 @@ int mfma_min_targets()
     return v;
 }
 
+// Single-GPU loop: final sum, step and pose update in one launch (k_finish_step_transform).
+// ICPMI_FUSE_FINISH=0 keeps the two separate kernels (the A/B knob of scripts/ab_fuse_finish.sh);
+// ICPMI_FUSE_BLOCKS sets the number of workgroups (each repeats the final sum).
+bool fuse_finish_enabled()
+{
+    static const bool v = [] {
+        const char *e = getenv("ICPMI_FUSE_FINISH");
+        return !(e && e[0] == '0' && e[1] == '\0');
+    }();
+    return v;
+}
+int finish_transform_blocks(int n)
+{
+    static const int cap = [] {
+        if (const char *e = getenv("ICPMI_FUSE_BLOCKS")) {
+            const long x = strtol(e, nullptr, 10);
+            if (x >= 1 && x <= 2048) return (int)x;
+        }
+        return 32;
+    }();
+    return std::max(1, std::min(cap, (n + kFinishThreads - 1) / kFinishThreads));
+}
+
 // Choose and prepare the search engine for a target cloud (once per call: the target does
 // not move).  Both engines return the same indices; AUTO takes the MFMA engine once the
 // pair count makes its fixed costs (Morton sort, operand packing, resolve) worthwhile.
@@ -756,6 +779,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     auto iteration = [&](int final_pass, int *progress, int ticket) -> int {
         int r2;
         const bool fuse_step = sharded && !pruned && n > 0 && !final_pass;
+        const bool fuse_finish = !sharded && !pruned && n > 0 && !final_pass && fuse_finish_enabled();
         if (n > 0 && fused) {
             if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, st, d_tgt, nrm, partials,
                                      pruned ? pass_no : -1))) return r2;
@@ -783,12 +807,18 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                     hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, st, hist, final_pass, progress, ticket,
                                        ctx->n_ranks);
                 }
+            } else if (fuse_finish) { // final sum + step + pose update of the rows in one launch
+                IcpState *other = st == ctx->d_state ? ctx->d_state + 1 : ctx->d_state;
+                hipLaunchKernelGGL(k_finish_step_transform, dim3(finish_transform_blocks(n)), dim3(kFinishThreads), 0, s,
+                                   (const double *)partials, rblocks, n, (const double *)cur, cur, n,
+                                   (const IcpState *)st, other, hist, progress, ticket);
+                st = other;
             } else {
                 hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
                                    st, hist, final_pass, progress, ticket);
             }
         }
-        if (!final_pass && n > 0 && !fuse_step) {
+        if (!final_pass && n > 0 && !fuse_step && !fuse_finish) {
             Range range("icpmi:transform");
             StageTimer t(ctx, ST_TRANSFORM);
             if (pruned) // + each block's box and its exact distance bound to this iteration's neighbours

@@ -7,6 +7,9 @@
 //   k_finish / k_step fixed-order final sum, error, convergence test, LDLT solve,
 //                     Rodrigues, pose accumulation (icp.hpp:207-231)
 //   k_transform       cloud * R^T + t^T (icp.hpp:174-176,225-226)
+//   k_finish_step_transform / k_step_transform
+//                     the loop's fused forms: final sum + step + pose update of the rows in one
+//                     launch (single GPU) / step + pose update behind the all-reduce (sharded)
 //
 // All arithmetic that decides an index or a flag is fp64 in the reference's operation
 // order (no FMA contraction in this TU).  Reductions use wave shuffles + LDS and a fixed
@@ -297,10 +300,13 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step(const double *__
                                                      double *history, int final_pass, int *progress,
                                                      int ticket)
 {
-    __shared__ IcpState ls;
+    __shared__ IcpState ls, sums; // `sums`: only its sums[] are used
+    // the state and the partial rows are requested together (one round trip instead of two); the
+    // sums are taken over only if the loop has not ended
     state_copy(&ls, st);
+    finish_sums(partials, nblocks, n_local, &sums);
     __syncthreads();
-    if (!ls.done) finish_sums(partials, nblocks, n_local, &ls);
+    if (!ls.done && threadIdx.x < kNumSums) ls.sums[threadIdx.x] = sums.sums[threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0) {
         step_update(&ls, history, final_pass);
@@ -383,6 +389,47 @@ __global__ __launch_bounds__(256) void k_step_transform(const double *in, double
     const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        out[3 * i] = ((x * r00 + y * r01) + z * r02) + t0;
+        out[3 * i + 1] = ((x * r10 + y * r11) + z * r12) + t1;
+        out[3 * i + 2] = ((x * r20 + y * r21) + z * r22) + t2;
+    }
+}
+
+// single GPU, two launches fewer per iteration: k_finish_step and k_transform in one kernel, on the
+// same footing as k_step_transform.  EVERY workgroup sums all partial rows itself (same rows, same
+// order, same bits: a 400 KB read out of the L2 at 100k points, 50 KB at the 7k points of a filtered
+// scan), repeats the step on its own LDS copy of the state and moves its share of the points;
+// workgroup 0 alone records the history entry, publishes the progress word and stores the new state
+// into the other state buffer.  No workgroup waits for another one.
+__global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform(
+    const double *__restrict__ partials, int nblocks, int n_local, const double *in, double *out, int n,
+    const IcpState *sin, IcpState *sout, double *history, int *progress, int ticket)
+{
+    __shared__ IcpState ls, sums; // `sums`: only its sums[] are used
+    // The kernel is a chain of memory round trips, so everything that does not depend on the state
+    // is requested first: this thread's first point, and the partial rows (summed whether or not
+    // the loop has ended; the sums are taken over only if it has not, like k_finish_step).
+    const int i0 = blockIdx.x * kFinishThreads + threadIdx.x;
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (i0 < n) x = in[3 * i0], y = in[3 * i0 + 1], z = in[3 * i0 + 2];
+    state_copy(&ls, sin);
+    finish_sums(partials, nblocks, n_local, &sums);
+    __syncthreads();
+    if (!ls.done && threadIdx.x < kNumSums) ls.sums[threadIdx.x] = sums.sums[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        step_update(&ls, blockIdx.x == 0 ? history : nullptr, 0);
+        if (blockIdx.x == 0) publish_progress(progress, ticket, ls.done);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) state_copy(sout, &ls);
+    if (ls.done) return; // the loop ended before or in this step: the source stays where it is (icp.hpp:210-217)
+    const double *T = ls.delta;
+    const double r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3];
+    const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
+    const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
+    for (int i = i0; i < n; i += gridDim.x * kFinishThreads) {
+        if (i != i0) x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
         out[3 * i] = ((x * r00 + y * r01) + z * r02) + t0;
         out[3 * i + 1] = ((x * r10 + y * r11) + z * r12) + t1;
         out[3 * i + 2] = ((x * r20 + y * r21) + z * r22) + t2;

@@ -835,3 +835,39 @@ def test_context_churn_does_not_leak_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+# ------------------------------------------------------------------ loop kernels: fused vs separate
+def test_fused_finish_kernel_gives_the_separate_kernels_bits():
+    """The single-GPU loop's k_finish_step_transform (default) against k_finish_step + k_transform
+    (ICPMI_FUSE_FINISH=0): same sums in the same order, same step, same point update -- the pose, the
+    history and the correspondences must agree bit for bit.  The knob is read once per process, so
+    each leg is a child process; clouds of 300 (one workgroup, exact engine below 256 targets is not
+    reached), 5,000 and 40,000 points (several workgroups each repeating the final sum)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r'''
+import sys, json, zlib
+sys.path.insert(0, %r)
+import numpy as np
+from lidar_slam_from_scratch_amd import capi, synth
+ctx = capi.Context(device=0)
+out = {}
+for n in (300, 5000, 40000):
+    src, tgt, _ = synth.c3_uniform(n) if n > 5000 else synth.c1_room_corner(n)
+    res, hist = ctx.align(src, tgt, capi.Context.make_config(max_iterations=12, tolerance=1e-7))
+    out[str(n)] = {"T": [float.hex(v) for v in res.transformation[:]], "hist": [float.hex(v) for v in hist],
+                   "iters": res.num_iterations, "converged": int(res.converged)}
+print(json.dumps(out))
+''' % root
+    legs = {}
+    for knob in ("0", "1"):
+        env = dict(os.environ, ICPMI_FUSE_FINISH=knob)
+        r = subprocess.run([sys.executable, "-c", child], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        legs[knob] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert legs["0"] == legs["1"]
+    assert all(v["iters"] >= 2 for v in legs["1"].values())
