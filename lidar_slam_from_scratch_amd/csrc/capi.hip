@@ -395,6 +395,20 @@ int resolve_blocks(int n)
     return (n + per - 1) / per;
 }
 
+// Diagnostic build (-DICPMI_COARSE_CLOCKS, scripts/coarse_clock.py): the all-pairs 1-NN pass stamps its clocks
+// into the (idle) slot-minimum buffer; icpmi_debug_coarse_clocks copies them out.  Null in the product build.
+float *coarse_clock_buffer(icpmi_ctx *ctx, int n, int splits)
+{
+#ifdef ICPMI_COARSE_CLOCKS
+    const size_t need = sizeof(unsigned long long) * 4 * (size_t)((n + kCoarseQueries - 1) / kCoarseQueries) * (size_t)splits;
+    if (reserve(ctx, ctx->slotmin, need) != ICPMI_OK) return nullptr;
+    return (float *)ctx->slotmin.p;
+#else
+    (void)ctx, (void)n, (void)splits;
+    return nullptr;
+#endif
+}
+
 int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx, double *d_d2,
                    const IcpState *st, const double *d_tgt = nullptr, const double *d_nrm = nullptr,
                    double *d_partials = nullptr, int pruned_pass = -1)
@@ -421,7 +435,7 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
         } else {
             hipLaunchKernelGGL((k_nn_coarse<0, kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
                                dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,
-                               (float2 *)ctx->coarse.p, (float *)nullptr, st);
+                               (float2 *)ctx->coarse.p, coarse_clock_buffer(ctx, n, splits), st);
         }
         ctx->prof.nn_coarse_blocks += (int64_t)((n + kCoarseQueries - 1) / kCoarseQueries) * splits;
     }
@@ -1785,5 +1799,16 @@ int icpmi_get_profile(icpmi_ctx *ctx, icpmi_profile *out)
     *out = ctx->prof;
     return ICPMI_OK;
 }
+
+#ifdef ICPMI_COARSE_CLOCKS
+// diagnostic build only: the stamps of the last all-pairs 1-NN pass (4 words per workgroup:
+// s_memtime, s_memrealtime at its start and at its end)
+int icpmi_debug_coarse_clocks(icpmi_ctx *ctx, unsigned long long *out, int64_t words)
+{
+    if (!ctx || !out || (size_t)words * 8 > ctx->slotmin.cap) return ICPMI_ERR_ARG;
+    if (hipMemcpy(out, ctx->slotmin.p, (size_t)words * 8, hipMemcpyDeviceToHost) != hipSuccess) return ICPMI_ERR_HIP;
+    return ICPMI_OK;
+}
+#endif
 
 } // extern "C"

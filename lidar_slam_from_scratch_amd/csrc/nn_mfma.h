@@ -383,104 +383,83 @@ __device__ __forceinline__ float tag_low5(float x, unsigned tag)
 // QT = 32-query tiles per wave (even); WAVES = waves per workgroup.  (Tried and dropped, see
 // scripts/micro/README.md: issuing a tile's min3 one tile behind its MFMAs, keeping the next B chunk
 // in flight in registers, QT = 4: none beat this form, all cost occupancy.)
-// One (query block, split) unit of the coarse pass: 512 queries against 2048 targets.
-// QS = 0: queries are rows of an N x 3 array; QS > 0 is not a template value but the runtime
-// component stride of an SoA array (x[0..n) | y | z, the layout of the sorted target) when QSOA.
-template <int MODE, int QT, int WAVES, bool QSOA = false>
-__device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int s, const int nsplits,
-                                            const double *__restrict__ qry, const int n, const size_t qstride,
-                                            const uint4 *__restrict__ Bpack,
-                                            const SplitFrame *__restrict__ frames,
-                                            float2 *__restrict__ coarse, float *__restrict__ slotmin)
+//
+// The three parts of a wave's work on 32*QT queries against one split, shared by the kernels below.
+
+// A operands.  Each lane builds the 16-slot bf16 row of ONE query (lane-per-query: coalesced fp64
+// loads, pieces computed once), rows go through `rows` (64 rows x 32 B of LDS private to the
+// wave), and every lane picks up its fragment: row l&31 of the tile, slots 8*(l>>5) .. +7.
+// QSOA: the queries are an SoA array (x[0..n) | y | z with component stride `qstride`, the layout of
+// the sorted target) instead of the rows of an N x 3 array.
+template <int QT, bool QSOA>
+__device__ __forceinline__ void coarse_build_a(uint4 *rows, const int lane, const int q0,
+                                               const double *__restrict__ qry, const int n, const size_t qstride,
+                                               const double c0, const double c1, const double c2,
+                                               bf16x8 (&afrag)[QT], float (&pn)[QT / 2])
 {
-    constexpr int THREADS = 64 * WAVES;
-    constexpr int CHUNK16 = kChunkTiles * 64;  // uint4 per staged chunk (32 KiB)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q0 = (bx * WAVES + wave) * (kTile * QT);
-    const double c0 = frames[s].c[0], c1 = frames[s].c[1], c2 = frames[s].c[2];
+#pragma unroll
+    for (int gq = 0; gq < QT / 2; ++gq) {
+        const int iq = q0 + gq * 64 + lane < n ? q0 + gq * 64 + lane : n - 1;
+        const float px = (float)((QSOA ? qry[iq] : qry[3 * iq]) - c0),
+                    py = (float)((QSOA ? qry[qstride + iq] : qry[3 * iq + 1]) - c1),
+                    pz = (float)((QSOA ? qry[2 * qstride + iq] : qry[3 * iq + 2]) - c2);
+        unsigned xh, xm, yh, ym, zh, zm;
+        split2(px, xh, xm);
+        split2(py, yh, ym);
+        split2(pz, zh, zm);
+        {   // |P|^2 of the REPRESENTED point (h + m: exact in fp32), see k_pack_targets
+            const float tx = __uint_as_float(xh << 16) + __uint_as_float(xm << 16);
+            const float ty = __uint_as_float(yh << 16) + __uint_as_float(ym << 16);
+            const float tz = __uint_as_float(zh << 16) + __uint_as_float(zm << 16);
+            pn[gq] = (tx * tx + ty * ty) + tz * tz;
+        }
+        // leading piece of |P|^2 (truncated: exact difference) goes through the matrix core,
+        // the epilogue adds the rest
+        const unsigned pnh = __float_as_uint(pn[gq]) >> 16;
+        pn[gq] -= __uint_as_float(pnh << 16);
+        const unsigned one = 0x3f80u;
+        // slots: x: h h m m, y: h h m m | z: h h m m, 1 1 1 |P|^2
+        rows[lane * 2 + 0] = make_uint4(xh | (xh << 16), xm | (xm << 16), yh | (yh << 16), ym | (ym << 16));
+        rows[lane * 2 + 1] = make_uint4(zh | (zh << 16), zm | (zm << 16), one | (one << 16), one | (pnh << 16));
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint4 f = rows[(t * 32 + (lane & 31)) * 2 + (lane >> 5)];
+            afrag[gq * 2 + t] = __builtin_bit_cast(bf16x8, f);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
-    // A operands.  Each lane builds the 16-slot bf16 row of ONE query (lane-per-query:
-    // coalesced fp64 loads, pieces computed once), rows go through LDS, and every lane
-    // picks up its fragment: row l&31 of the tile, slots 8*(l>>5) .. +7.
-    bf16x8 afrag[QT];
-    float pn[QT / 2];
-    {
-        uint4 *rows = lds + wave * (64 * 2); // 64 rows x 32 B
+// NT target tiles (1 KiB each, at `tiles`) against the wave's QT query tiles: one MFMA per (query
+// tile, target tile), running minimum per (row, column) with one v_min3_f32 per two results.
+// Fully unrolled: immediate LDS offsets.
+template <int QT, int NT>
+__device__ __forceinline__ void coarse_tiles(const uint4 *tiles, const int lane, const bf16x8 (&afrag)[QT],
+                                             f32x16 (&m)[QT], const f32x16 &zero)
+{
 #pragma unroll
-        for (int gq = 0; gq < QT / 2; ++gq) {
-            const int iq = q0 + gq * 64 + lane < n ? q0 + gq * 64 + lane : n - 1;
-            const float px = (float)((QSOA ? qry[iq] : qry[3 * iq]) - c0),
-                        py = (float)((QSOA ? qry[qstride + iq] : qry[3 * iq + 1]) - c1),
-                        pz = (float)((QSOA ? qry[2 * qstride + iq] : qry[3 * iq + 2]) - c2);
-            unsigned xh, xm, yh, ym, zh, zm;
-            split2(px, xh, xm);
-            split2(py, yh, ym);
-            split2(pz, zh, zm);
-            {   // |P|^2 of the REPRESENTED point (h + m: exact in fp32), see k_pack_targets
-                const float tx = __uint_as_float(xh << 16) + __uint_as_float(xm << 16);
-                const float ty = __uint_as_float(yh << 16) + __uint_as_float(ym << 16);
-                const float tz = __uint_as_float(zh << 16) + __uint_as_float(zm << 16);
-                pn[gq] = (tx * tx + ty * ty) + tz * tz;
-            }
-            // leading piece of |P|^2 (truncated: exact difference) goes through the matrix core,
-            // the epilogue adds the rest
-            const unsigned pnh = __float_as_uint(pn[gq]) >> 16;
-            pn[gq] -= __uint_as_float(pnh << 16);
-            const unsigned one = 0x3f80u;
-            // slots: x: h h m m, y: h h m m | z: h h m m, 1 1 1 |P|^2
-            rows[lane * 2 + 0] = make_uint4(xh | (xh << 16), xm | (xm << 16), yh | (yh << 16), ym | (ym << 16));
-            rows[lane * 2 + 1] = make_uint4(zh | (zh << 16), zm | (zm << 16), one | (one << 16), one | (pnh << 16));
-            __builtin_amdgcn_wave_barrier();
+    for (int tt = 0; tt < NT; tt += 2) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, tiles[tt * 64 + lane]);
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, tiles[(tt + 1) * 64 + lane]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const uint4 f = rows[(t * 32 + (lane & 31)) * 2 + (lane >> 5)];
-                afrag[gq * 2 + t] = __builtin_bit_cast(bf16x8, f);
-            }
-            __builtin_amdgcn_wave_barrier();
+        for (int t = 0; t < QT; ++t) {
+            const f32x16 da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[t], b0, zero, 0, 0, 0);
+            const f32x16 db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[t], b1, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[t][r] = min3f(m[t][r], da[r], db[r]);
         }
     }
-    f32x16 m[QT];
-#pragma unroll
-    for (int t = 0; t < QT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m[t][r] = kBig;
-    f32x16 zero;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+}
 
-#if defined(ICPMI_COARSE_PRIO) && ICPMI_COARSE_PRIO == 1 /* A/B: static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4) */
-    if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
-#elif defined(ICPMI_COARSE_PRIO) && ICPMI_COARSE_PRIO == 2
-    if (wave & 1) __builtin_amdgcn_s_setprio(1);
-#endif
-    // B operands: 2 chunks of 32 tiles through one 32 KiB LDS buffer
-    const uint4 *src = Bpack + (size_t)s * (kSplitTiles * 64);
-#pragma unroll 1
-    for (int chunk = 0; chunk < kSplitTiles / kChunkTiles; ++chunk) {
-        __syncthreads(); // A rows / previous chunk no longer needed
-#pragma unroll
-        for (int e = 0; e < CHUNK16 / THREADS; ++e)
-            lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
-        __syncthreads();
-#pragma unroll
-        for (int tt = 0; tt < kChunkTiles; tt += 2) { // fully unrolled: immediate LDS offsets
-            const bf16x8 b0 = __builtin_bit_cast(bf16x8, lds[tt * 64 + lane]);
-            const bf16x8 b1 = __builtin_bit_cast(bf16x8, lds[(tt + 1) * 64 + lane]);
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                const f32x16 da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[t], b0, zero, 0, 0, 0);
-                const f32x16 db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[t], b1, zero, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m[t][r] = min3f(m[t][r], da[r], db[r]);
-            }
-        }
-    }
-
-    // epilogue.  Transpose through LDS, one 32-query tile at a time (row stride 36 floats:
-    // conflict-free ds_read_b128): lane l then owns query l&31 and columns 16*(l>>5).. +15;
-    // + |P|^2, per-lane top-2, the two halves merge with one cross-lane step.
-    __syncthreads(); // every wave is done with the B operands
-    float *sc = reinterpret_cast<float *>(lds) + wave * (32 * 36);
+// Epilogue.  Transpose through `sc` (32 x 36 floats of LDS private to the wave; row stride 36:
+// conflict-free ds_read_b128), one 32-query tile at a time: lane l then owns query l&31 and
+// columns 16*(l>>5).. +15; + |P|^2, per-lane top-2, the two halves merge with one cross-lane step.
+template <int MODE, int QT>
+__device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const int q0, const int s, const int nsplits,
+                                                const int n, const f32x16 (&m)[QT], const float (&pn)[QT / 2],
+                                                float2 *__restrict__ coarse, float *__restrict__ slotmin)
+{
     const int ql = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -550,6 +529,73 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
     }
 }
 
+// One (query block, split) unit of the coarse pass: 512 queries against 2048 targets, the targets
+// staged through one 32 KiB LDS buffer in two chunks.
+template <int MODE, int QT, int WAVES, bool QSOA = false>
+__device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int s, const int nsplits,
+                                            const double *__restrict__ qry, const int n, const size_t qstride,
+                                            const uint4 *__restrict__ Bpack,
+                                            const SplitFrame *__restrict__ frames,
+                                            float2 *__restrict__ coarse, float *__restrict__ slotmin)
+{
+    constexpr int THREADS = 64 * WAVES;
+    constexpr int CHUNK16 = kChunkTiles * 64;  // uint4 per staged chunk (32 KiB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = (bx * WAVES + wave) * (kTile * QT);
+#ifdef ICPMI_COARSE_CLOCKS /* diagnostic build only (scripts/coarse_clock.py): the clock the chip holds inside this
+                              kernel = d(s_memtime) / d(s_memrealtime) x 100 MHz; the 1-NN pass gets a stamp buffer
+                              through the otherwise unused `slotmin` argument */
+    unsigned long long ck0 = 0, rk0 = 0;
+    if (MODE == 0 && slotmin && threadIdx.x == 0) {
+        ck0 = __builtin_amdgcn_s_memtime();
+        rk0 = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    const double c0 = frames[s].c[0], c1 = frames[s].c[1], c2 = frames[s].c[2];
+
+    bf16x8 afrag[QT];
+    float pn[QT / 2];
+    coarse_build_a<QT, QSOA>(lds + wave * (64 * 2), lane, q0, qry, n, qstride, c0, c1, c2, afrag, pn);
+    f32x16 m[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[t][r] = kBig;
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+
+#if defined(ICPMI_COARSE_PRIO) && ICPMI_COARSE_PRIO == 1 /* A/B: static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4) */
+    if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+#elif defined(ICPMI_COARSE_PRIO) && ICPMI_COARSE_PRIO == 2
+    if (wave & 1) __builtin_amdgcn_s_setprio(1);
+#endif
+    // B operands: 2 chunks of 32 tiles through one 32 KiB LDS buffer
+    const uint4 *src = Bpack + (size_t)s * (kSplitTiles * 64);
+#pragma unroll 1
+    for (int chunk = 0; chunk < kSplitTiles / kChunkTiles; ++chunk) {
+        __syncthreads(); // A rows / previous chunk no longer needed
+#pragma unroll
+        for (int e = 0; e < CHUNK16 / THREADS; ++e)
+            lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
+        __syncthreads();
+        coarse_tiles<QT, kChunkTiles>(lds, lane, afrag, m, zero);
+    }
+
+    __syncthreads(); // every wave is done with the B operands
+    coarse_epilogue<MODE, QT>(reinterpret_cast<float *>(lds) + wave * (32 * 36), lane, q0, s, nsplits, n, m, pn, coarse,
+                              slotmin);
+#ifdef ICPMI_COARSE_CLOCKS
+    if (MODE == 0 && slotmin && threadIdx.x == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(slotmin) + 4 * ((size_t)bx * nsplits + s);
+        o[0] = ck0;
+        o[1] = rk0;
+        o[2] = __builtin_amdgcn_s_memtime();
+        o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
 template <int WAVES>
 struct CoarseLds {
     static constexpr int CHUNK16 = kChunkTiles * 64;
@@ -569,6 +615,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
     coarse_unit<MODE, QT, WAVES>(lds, blockIdx.x, blockIdx.y, gridDim.y, qry, n, 0, Bpack, frames, coarse, slotmin);
 }
+
+// (Measured and not kept, scripts/micro/README.md: a RESIDENT form -- one 16-wave workgroup per CU stages a
+// split's 64 KiB of operands once and walks over blocks of 1,024 queries with no barrier after the
+// staging, A rows and epilogue transposes in wave-private LDS.  315 us against 311 us on C3: the
+// per-unit form's staging phases and barriers are not what its time goes to.)
 
 // Pruned engine: the units that survived the box test (k_transform_bounds) are listed in
 // `work` (unit = block * nsplits + split, any order); a fixed grid strides over the list, so
