@@ -236,6 +236,42 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
                            int32_t history_cap, icpmi_stream_info *info);
 int icpmi_stream_reset(icpmi_ctx *ctx);   /* forget the resident frame (a new sequence starts) */
 
+/* The map side of SlamNode::process_frame, once the caller has formed new_pose = poses.back() * delta
+ * (slam_viz/src/ros/slam_node.cpp:142-153):
+ *     world = curr * new_pose.R^T + new_pose.t^T                    :147
+ *     update_occupancy_grid(world, new_pose.t)                      :153, :211-221
+ * update_occupancy_grid marks, for every world point with height_min <= z <= height_max and
+ * 0.5 <= hypot(x - sensor.x, y - sensor.y) <= max_range, the 2-D cell (floor(x / resolution),
+ * floor(y / resolution)) in a set of cells (std::unordered_set<GridCell>, slam_node.hpp:45-58); the
+ * defaults are OccupancyGridConfig's (slam_node.hpp:35-40).  Here the set lives in device memory
+ * as a sorted array of unique cells that every update merges into.  Beyond the reference: a point
+ * whose quotient is not finite or does not fit an int (undefined static_cast there) marks nothing. */
+typedef struct {
+    double resolution;   /* 0.2 */
+    double height_min;   /* 0.3 */
+    double height_max;   /* 2.0 */
+    double max_range;    /* 40.0 */
+} icpmi_grid_config;
+void icpmi_grid_config_default(icpmi_grid_config *grid);
+/* world points in host memory (n x 3) and the sensor position; *n_cells (may be NULL: no wait for
+ * the device then) receives the size of the set after the update. */
+int icpmi_occupancy_update(icpmi_ctx *ctx, const double *world_xyz, int64_t n, const double sensor_xyz[3],
+                           const icpmi_grid_config *grid, int64_t *n_cells);
+/* Same with the points in device memory. */
+int icpmi_occupancy_update_device(icpmi_ctx *ctx, const double *d_world_xyz, int64_t n, const double sensor_xyz[3],
+                                  const icpmi_grid_config *grid, int64_t *n_cells);
+/* The set: cells_xy[2 i], cells_xy[2 i + 1] = (x, y) of cell i, sorted by x then y.  cells_xy may be
+ * NULL (only *n_cells is set); fewer than *n_cells entries of capacity is ICPMI_ERR_CAPACITY.  What
+ * cells_to_occupancy_grid_msg (slam_node.cpp:279-297) rasterises. */
+int icpmi_occupancy_cells(icpmi_ctx *ctx, int32_t *cells_xy, int64_t cap_cells, int64_t *n_cells);
+int icpmi_occupancy_clear(icpmi_ctx *ctx);   /* occupied_cells_.clear() (slam_node.cpp:224) */
+/* Both steps on the scan the last icpmi_stream_push* left resident (it never came to the host):
+ * pose = new_pose, row-major 4 x 4.  world_out (host, may be NULL) receives the n_filtered x 3 world
+ * points (what publish_current_scan sends, :155), *n_world their number; grid may be NULL (no grid
+ * update; *n_cells is then the current size).  One wait for everything the call returns. */
+int icpmi_stream_map_update(icpmi_ctx *ctx, const double pose[16], const icpmi_grid_config *grid,
+                            double *world_out, int64_t world_cap, int64_t *n_world, int64_t *n_cells);
+
 /* Replaces ScanContext::compute (core/scan_context.hpp:44-82): 20 rings x 60 sectors max-height
  * descriptor, row-major desc_out[ring * 60 + sector], empty bins 0. */
 #define ICPMI_SC_RINGS 20

@@ -25,6 +25,8 @@ EXPORTS = [
     "icpmi_scan_context", "icpmi_scan_context_distances", "icpmi_load_cloud", "icpmi_load_cloud_device",
     "icpmi_upload_points_f32", "icpmi_discover_frames", "icpmi_estimate_normals_rows",
     "icpmi_stream_push", "icpmi_stream_push_host", "icpmi_stream_push_file", "icpmi_stream_reset",
+    "icpmi_grid_config_default", "icpmi_occupancy_update", "icpmi_occupancy_update_device", "icpmi_occupancy_cells",
+    "icpmi_occupancy_clear", "icpmi_stream_map_update",
     "icpmi_reset_profile", "icpmi_get_profile",
 ]
 
@@ -64,6 +66,12 @@ class StreamInfo(C.Structure):
 
 
 STREAM_REGISTERED, STREAM_FIRST_FRAME, STREAM_TOO_FEW_POINTS = 0, 1, 2
+
+
+class GridConfig(C.Structure):
+    """OccupancyGridConfig (slam_node.hpp:35-40)"""
+    _fields_ = [("resolution", C.c_double), ("height_min", C.c_double), ("height_max", C.c_double), ("max_range", C.c_double)]
+
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
@@ -164,6 +172,13 @@ def load_library(path=None):
     L.icpmi_stream_push_file.argtypes = [vp, C.c_char_p, C.c_double, C.c_int64, C.POINTER(Config), C.POINTER(Result), dp,
                                          C.c_int32, C.POINTER(StreamInfo)]
     L.icpmi_stream_reset.argtypes = [vp]
+    L.icpmi_grid_config_default.argtypes = [C.POINTER(GridConfig)]
+    L.icpmi_grid_config_default.restype = None
+    L.icpmi_occupancy_update.argtypes = [vp, dp, C.c_int64, dp, C.POINTER(GridConfig), i64p]
+    L.icpmi_occupancy_update_device.argtypes = [vp, vp, C.c_int64, dp, C.POINTER(GridConfig), i64p]
+    L.icpmi_occupancy_cells.argtypes = [vp, C.POINTER(C.c_int32), C.c_int64, i64p]
+    L.icpmi_occupancy_clear.argtypes = [vp]
+    L.icpmi_stream_map_update.argtypes = [vp, dp, C.POINTER(GridConfig), dp, C.c_int64, i64p, i64p]
     L.icpmi_scan_context.argtypes = [vp, dp, C.c_int64, dp]
     L.icpmi_scan_context_distances.argtypes = [vp, dp, dp, C.c_int64, dp]
     L.icpmi_comm_unique_id.argtypes = [vp, vp]
@@ -384,6 +399,59 @@ class Context:
 
     def stream_reset(self):
         self._check(self._lib.icpmi_stream_reset(self._h))
+
+    @staticmethod
+    def make_grid_config(resolution=None, height_min=None, height_max=None, max_range=None):
+        g = GridConfig()
+        load_library().icpmi_grid_config_default(C.byref(g))
+        for name, v in (("resolution", resolution), ("height_min", height_min), ("height_max", height_max),
+                        ("max_range", max_range)):
+            if v is not None:
+                setattr(g, name, float(v))
+        return g
+
+    def occupancy_update(self, world, sensor, grid=None):
+        """update_occupancy_grid(world, sensor) (slam_node.cpp:211-221) into the context's cell set -> its size"""
+        pts = _f64(world) if len(world) else np.zeros((0, 3))
+        sx = np.ascontiguousarray(sensor, dtype=np.float64).reshape(3)
+        g = grid if grid is not None else self.make_grid_config()
+        n = C.c_int64(0)
+        self._check(self._lib.icpmi_occupancy_update(self._h, _dp(pts), pts.shape[0], _dp(sx), C.byref(g), C.byref(n)))
+        return n.value
+
+    def occupancy_update_device(self, ptr, n_rows, sensor, grid=None):
+        sx = np.ascontiguousarray(sensor, dtype=np.float64).reshape(3)
+        g = grid if grid is not None else self.make_grid_config()
+        n = C.c_int64(0)
+        self._check(self._lib.icpmi_occupancy_update_device(self._h, C.c_void_p(ptr), n_rows, _dp(sx), C.byref(g), C.byref(n)))
+        return n.value
+
+    def occupancy_cells(self):
+        """the set as an (n, 2) int32 array of (x, y), sorted by x then y"""
+        n = C.c_int64(0)
+        self._check(self._lib.icpmi_occupancy_cells(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 2), dtype=np.int32)
+        if n.value:
+            self._check(self._lib.icpmi_occupancy_cells(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), n.value, C.byref(n)))
+        return out
+
+    def occupancy_clear(self):
+        self._check(self._lib.icpmi_occupancy_clear(self._h))
+
+    def stream_map_update(self, pose, grid=None, want_world=True, update_grid=True):
+        """slam_node.cpp:147-153 on the scan the last stream_push* left resident: (world points or None, cells in the set)"""
+        T = np.ascontiguousarray(pose, dtype=np.float64).reshape(16)
+        nw, nc = C.c_int64(0), C.c_int64(0)
+        g = (grid if grid is not None else self.make_grid_config()) if update_grid else None
+        world = None
+        if want_world:
+            # the row count is the filtered scan's, known to the caller from the push; ask first to stay general
+            self._check(self._lib.icpmi_stream_map_update(self._h, _dp(T), None, None, 0, C.byref(nw), C.byref(nc)))
+            world = np.empty((nw.value, 3))
+        self._check(self._lib.icpmi_stream_map_update(self._h, _dp(T), C.byref(g) if g is not None else None,
+                                                      _dp(world) if world is not None else None,
+                                                      world.shape[0] if world is not None else 0, C.byref(nw), C.byref(nc)))
+        return world, nc.value
 
     def scan_context(self, cloud):
         """scan_context.hpp:44-82 -> 20 x 60 descriptor"""

@@ -28,6 +28,7 @@
 #include "nn_mfma.h"
 #include "voxel.h"
 #include "scan_context.h"
+#include "occupancy.h"
 
 using namespace icpmi;
 
@@ -42,6 +43,8 @@ hipError_t run_lengths_u64(void *temp, size_t *temp_bytes, const unsigned long l
                            hipStream_t stream);
 hipError_t exclusive_sum_u32(void *temp, size_t *temp_bytes, const unsigned *in, unsigned *out, unsigned n,
                              hipStream_t stream);
+hipError_t sort_keys_u64(void *temp, size_t *temp_bytes, const unsigned long long *keys_in,
+                         unsigned long long *keys_out, unsigned n, hipStream_t stream);
 }
 
 namespace {
@@ -119,6 +122,9 @@ struct icpmi_ctx {
     DevBuf vox_keys, vox_vals, vox_out;             // voxel filter: 64-bit keys (in/out/unique), values + run data, result
     DevBuf stream_prev, stream_cur, f32_stage;      // odometry stream: previous / current filtered scan; float32 upload staging
     int64_t stream_prev_n = -1;                     // rows of stream_prev (-1: no frame yet)
+    DevBuf grid_set, grid_in, grid_out, grid_cnt, world; // occupancy grid: the set (sorted unique keys), {set, new keys}, sorted, run data; world points
+    int64_t grid_n = 0;                             // cells in grid_set
+    unsigned *h_grid = nullptr;                     // pinned: the set's size on its way back
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     DevBuf src_sort, blk_lists, work;         // pruned engine: Morton order of the source, per-block split lists, unit list
@@ -965,6 +971,49 @@ int voxel_downsample_device(icpmi_ctx *ctx, const double *d_pts, int n, double v
     return ICPMI_OK;
 }
 
+// update_occupancy_grid (slam_node.cpp:211-221) on device memory: keys of the new points behind the
+// set, one sort, one run-length pass; the set's new size is queued for the host (ctx->h_grid[0]) and
+// picked up by grid_finish after the caller's wait.
+int grid_update_queue(icpmi_ctx *ctx, const double *d_world, int n, const double sensor[3], const icpmi_grid_config *grid)
+{
+    if (!(grid->resolution > 0.0)) return fail(ctx, ICPMI_ERR_ARG, "grid resolution must be positive");
+    hipStream_t s = ctx->stream;
+    int rc;
+    const size_t total = (size_t)ctx->grid_n + (size_t)n;
+    if (total > (size_t)2000000000) return fail(ctx, ICPMI_ERR_ARG, "occupancy set too large");
+    if ((rc = reserve(ctx, ctx->grid_in, sizeof(unsigned long long) * std::max<size_t>(total, 1)))) return rc;
+    if ((rc = reserve(ctx, ctx->grid_out, sizeof(unsigned long long) * std::max<size_t>(total, 1)))) return rc;
+    if ((rc = reserve(ctx, ctx->grid_cnt, sizeof(unsigned) * (total + 16)))) return rc;
+    unsigned long long *in = (unsigned long long *)ctx->grid_in.p, *out = (unsigned long long *)ctx->grid_out.p;
+    unsigned *counts = (unsigned *)ctx->grid_cnt.p, *runs_d = counts + total, *count_d = runs_d + 1;
+    size_t b1 = 0, b2 = 0;
+    HIP_TRY(ctx, sort_keys_u64(nullptr, &b1, in, out, (unsigned)total, s));
+    HIP_TRY(ctx, run_lengths_u64(nullptr, &b2, out, (unsigned)total, in, counts, runs_d, s));
+    if ((rc = reserve(ctx, ctx->sort_tmp, std::max(b1, b2)))) return rc;
+    if (ctx->grid_n > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(in, ctx->grid_set.p, sizeof(unsigned long long) * (size_t)ctx->grid_n, hipMemcpyDeviceToDevice, s));
+    if (n > 0) {
+        GridParams g{sensor[0], sensor[1], grid->resolution, grid->height_min, grid->height_max, grid->max_range};
+        hipLaunchKernelGGL(k_grid_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_world, n, g, in + ctx->grid_n);
+    }
+    if (total > 0) {
+        HIP_TRY(ctx, sort_keys_u64(ctx->sort_tmp.p, &b1, in, out, (unsigned)total, s));
+        // unique keys -> the new set (grid_set is reallocated only when it must grow)
+        if ((rc = reserve(ctx, ctx->grid_set, sizeof(unsigned long long) * total))) return rc;
+        HIP_TRY(ctx, run_lengths_u64(ctx->sort_tmp.p, &b2, out, (unsigned)total, (unsigned long long *)ctx->grid_set.p, counts,
+                                     runs_d, s));
+        hipLaunchKernelGGL(k_grid_count, dim3(1), dim3(1), 0, s, (const unsigned long long *)ctx->grid_set.p,
+                           (const unsigned *)runs_d, count_d);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_grid, count_d, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    } else {
+        ctx->h_grid[0] = 0;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return ICPMI_OK;
+}
+// after the stream has been waited for
+void grid_finish(icpmi_ctx *ctx) { ctx->grid_n = (int64_t)ctx->h_grid[0]; }
+
 int validate_align(icpmi_ctx *ctx, const void *src, int64_t n_src, const void *tgt, int64_t n_tgt,
                    const icpmi_config *cfg, icpmi_result *result, double *hist, int32_t cap)
 {
@@ -1055,6 +1104,7 @@ int icpmi_create(const icpmi_options *opt, icpmi_ctx **out)
     if (hipMalloc((void **)&ctx->d_state, 2 * sizeof(IcpState)) != hipSuccess) return bail("hipMalloc state");
     if (hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
     if (hipHostMalloc((void **)&ctx->h_flags, sizeof(int32_t) * kFlagRing, hipHostMallocMapped) != hipSuccess) return bail("hipHostMalloc");
+    if (hipHostMalloc((void **)&ctx->h_grid, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
     memset(ctx->h_flags, 0, sizeof(int32_t) * kFlagRing);
     if (hipHostGetDevicePointer((void **)&ctx->d_flags, ctx->h_flags, 0) != hipSuccess) return bail("hipHostGetDevicePointer");
     *out = ctx;
@@ -1071,8 +1121,10 @@ void icpmi_destroy(icpmi_ctx *ctx)
                       &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out, &ctx->src_sort, &ctx->blk_lists, &ctx->work,
                       &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin,
                       &ctx->fb_list, &ctx->sort_keys, &ctx->sort_tmp, &ctx->tgt_sorted, &ctx->frames, &ctx->vox_keys,
-                      &ctx->vox_vals, &ctx->vox_out, &ctx->stream_prev, &ctx->stream_cur, &ctx->f32_stage})
+                      &ctx->vox_vals, &ctx->vox_out, &ctx->stream_prev, &ctx->stream_cur, &ctx->f32_stage, &ctx->grid_set,
+                      &ctx->grid_in, &ctx->grid_out, &ctx->grid_cnt, &ctx->world})
         release(*b);
+    if (ctx->h_grid) (void)hipHostFree(ctx->h_grid);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_hist) (void)hipHostFree(ctx->h_hist);
@@ -1674,6 +1726,106 @@ int icpmi_stream_push_host(icpmi_ctx *ctx, const double *raw_xyz, int64_t n_raw,
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_a.p, raw_xyz, sizeof(double) * 3 * (size_t)n_raw, hipMemcpyHostToDevice, ctx->stream));
     return icpmi_stream_push(ctx, (const double *)ctx->stage_a.p, n_raw, voxel_size, min_points, cfg, result, error_history,
                              history_cap, info);
+}
+
+// ---- the map side of process_frame (slam_node.cpp:147-153, :211-221) -------------------------------------
+void icpmi_grid_config_default(icpmi_grid_config *grid)
+{
+    if (!grid) return;
+    grid->resolution = 0.2;   // slam_node.hpp:36-39
+    grid->height_min = 0.3;
+    grid->height_max = 2.0;
+    grid->max_range = 40.0;
+}
+
+int icpmi_occupancy_update_device(icpmi_ctx *ctx, const double *d_world_xyz, int64_t n, const double sensor_xyz[3],
+                                  const icpmi_grid_config *grid, int64_t *n_cells)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if ((!d_world_xyz && n != 0) || !sensor_xyz || !grid) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n < 0 || n > 700000000) return fail(ctx, ICPMI_ERR_ARG, "n out of range");
+    Range range("icpmi:occupancy_update");
+    if ((rc = grid_update_queue(ctx, d_world_xyz, (int)n, sensor_xyz, grid))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    grid_finish(ctx);
+    if (n_cells) *n_cells = ctx->grid_n;
+    return ICPMI_OK;
+}
+
+int icpmi_occupancy_update(icpmi_ctx *ctx, const double *world_xyz, int64_t n, const double sensor_xyz[3],
+                           const icpmi_grid_config *grid, int64_t *n_cells)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if ((!world_xyz && n != 0) || !sensor_xyz || !grid) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n < 0 || n > 700000000) return fail(ctx, ICPMI_ERR_ARG, "n out of range");
+    if ((rc = reserve(ctx, ctx->world, sizeof(double) * 3 * (size_t)std::max<int64_t>(n, 1)))) return rc;
+    if (n > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->world.p, world_xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    return icpmi_occupancy_update_device(ctx, (const double *)ctx->world.p, n, sensor_xyz, grid, n_cells);
+}
+
+int icpmi_occupancy_cells(icpmi_ctx *ctx, int32_t *cells_xy, int64_t cap_cells, int64_t *n_cells)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!n_cells) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    *n_cells = ctx->grid_n;
+    if (!cells_xy || ctx->grid_n == 0) return ICPMI_OK;
+    if (cap_cells < ctx->grid_n)
+        return fail(ctx, ICPMI_ERR_CAPACITY, "output holds %lld cells, needs %lld", (long long)cap_cells, (long long)ctx->grid_n);
+    const int n = (int)ctx->grid_n;
+    if ((rc = reserve(ctx, ctx->grid_out, sizeof(int) * 2 * (size_t)n))) return rc;
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(k_grid_decode, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned long long *)ctx->grid_set.p, n,
+                       (int *)ctx->grid_out.p);
+    HIP_TRY(ctx, hipMemcpyAsync(cells_xy, ctx->grid_out.p, sizeof(int) * 2 * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipGetLastError());
+    return ICPMI_OK;
+}
+
+int icpmi_occupancy_clear(icpmi_ctx *ctx)
+{
+    if (!ctx) return ICPMI_ERR_NULL;
+    ctx->grid_n = 0;
+    return ICPMI_OK;
+}
+
+int icpmi_stream_map_update(icpmi_ctx *ctx, const double pose[16], const icpmi_grid_config *grid, double *world_out,
+                            int64_t world_cap, int64_t *n_world, int64_t *n_cells)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!pose) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (ctx->stream_prev_n < 0) return fail(ctx, ICPMI_ERR_ARG, "no resident frame: call icpmi_stream_push first");
+    const int n = (int)ctx->stream_prev_n;
+    if (n_world) *n_world = n;
+    if (world_out && world_cap < n)
+        return fail(ctx, ICPMI_ERR_CAPACITY, "world_out holds %lld rows, needs %d", (long long)world_cap, n);
+    Range range("icpmi:map_update");
+    hipStream_t s = ctx->stream;
+    if ((rc = reserve(ctx, ctx->world, sizeof(double) * 3 * (size_t)std::max(n, 1)))) return rc;
+    if (n > 0) {
+        // world = curr * R^T + t^T (slam_node.cpp:147), the resident filtered scan -> ctx->world
+        memset(ctx->h_state, 0, sizeof(IcpState));
+        memcpy(ctx->h_state->total, pose, sizeof(double) * 16);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state, ctx->h_state, sizeof(IcpState), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, (const double *)ctx->stream_prev.p,
+                           (double *)ctx->world.p, n, ctx->d_state, 1, 0);
+        if (world_out)
+            HIP_TRY(ctx, hipMemcpyAsync(world_out, ctx->world.p, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, s));
+    }
+    if (grid) {
+        const double sensor[3] = {pose[3], pose[7], pose[11]}; // new_pose.t() (slam_node.cpp:153)
+        if ((rc = grid_update_queue(ctx, (const double *)ctx->world.p, n, sensor, grid))) return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));   // the call's one wait: world points and the set's size
+    HIP_TRY(ctx, hipGetLastError());
+    if (grid) grid_finish(ctx);
+    if (n_cells) *n_cells = ctx->grid_n;
+    return ICPMI_OK;
 }
 
 int icpmi_scan_context(icpmi_ctx *ctx, const double *cloud_xyz, int64_t n, double *desc_out)

@@ -39,6 +39,13 @@ hipError_t run_lengths_u64(void *temp, size_t *temp_bytes, const unsigned long l
     return rocprim::run_length_encode(temp, *temp_bytes, keys, n, unique_out, counts_out, runs_out, stream);
 }
 
+// all 64 bits, keys only: the occupancy set (occupancy.h)
+hipError_t sort_keys_u64(void *temp, size_t *temp_bytes, const unsigned long long *keys_in,
+                         unsigned long long *keys_out, unsigned n, hipStream_t stream)
+{
+    return rocprim::radix_sort_keys(temp, *temp_bytes, keys_in, keys_out, n, 0u, 64u, stream);
+}
+
 hipError_t exclusive_sum_u32(void *temp, size_t *temp_bytes, const unsigned *in, unsigned *out, unsigned n,
                              hipStream_t stream)
 {

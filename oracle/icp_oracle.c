@@ -712,6 +712,35 @@ int orc_voxel_downsample(const double *pts, int n, double voxel_size, double *ou
 }
 
 /* ------------------------------------------------------------------------- */
+/* Occupancy grid insert (src/ros/slam_node.cpp:211-221, config slam_node.hpp:35-40) */
+/* ------------------------------------------------------------------------- */
+
+/* SlamNode::update_occupancy_grid(cloud, sensor): the cell every world point marks, or none.
+   keep[i] = 0 where the reference `continue`s (height, range) -- and, beyond the reference,
+   where its static_cast<int>(std::floor(x / resolution)) is undefined (non-finite quotient or
+   one outside int): such a point marks nothing here.  The reference's container is an
+   unordered_set: callers compare as sets. */
+void orc_occupancy_cells(const double *world_xyz, int n, const double sensor_xyz[3], double resolution,
+                         double height_min, double height_max, double max_range, int *cells_xy,
+                         unsigned char *keep)
+{
+    for (int i = 0; i < n; ++i) {
+        const double x = world_xyz[3 * i], y = world_xyz[3 * i + 1], z = world_xyz[3 * i + 2];
+        keep[i] = 0;
+        cells_xy[2 * i] = cells_xy[2 * i + 1] = 0;
+        if (z < height_min || z > height_max) continue;                                   /* :214 */
+        const double dx = x - sensor_xyz[0], dy = y - sensor_xyz[1];
+        const double r = sqrt(dx * dx + dy * dy);                                         /* :215 */
+        if (r > max_range || r < 0.5) continue;                                           /* :216 */
+        const double cx = floor(x / resolution), cy = floor(y / resolution);              /* :217-218 */
+        if (!(fabs(cx) <= 2147483646.0) || !(fabs(cy) <= 2147483646.0)) continue;         /* UB in the reference */
+        cells_xy[2 * i] = (int)cx;
+        cells_xy[2 * i + 1] = (int)cy;
+        keep[i] = 1;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Scan Context (scan_context.hpp)                                           */
 /* ------------------------------------------------------------------------- */
 

@@ -75,6 +75,11 @@ int orc_voxel_downsample(const double *points_xyz, int n, double voxel_size, dou
  * row-major desc[ring*60 + sector]; empty bins 0. */
 #define ORC_SC_RINGS 20
 #define ORC_SC_SECTORS 60
+/* update_occupancy_grid (src/ros/slam_node.cpp:211-221): per point the grid cell it marks (keep = 1) or none */
+void orc_occupancy_cells(const double *world_xyz, int n, const double sensor_xyz[3], double resolution,
+                         double height_min, double height_max, double max_range, int *cells_xy,
+                         unsigned char *keep);
+
 void orc_scan_context(const double *cloud_xyz, int n, double *desc /* 20*60 */);
 /* scan_context.hpp:90-101,121-142 (distance): min over the 60 column shifts of 1 - cosine. */
 double orc_scan_context_distance(const double *a, const double *b);

@@ -65,6 +65,8 @@ def lib():
         L.orc_voxel_downsample.restype = C.c_int
         L.orc_voxel_downsample.argtypes = [dp, C.c_int, C.c_double, dp]
         L.orc_scan_context.argtypes = [dp, C.c_int, dp]
+        L.orc_occupancy_cells.argtypes = [dp, C.c_int, dp, C.c_double, C.c_double, C.c_double, C.c_double, ip,
+                                          C.POINTER(C.c_ubyte)]
         L.orc_scan_context_distance.restype = C.c_double
         L.orc_scan_context_distance.argtypes = [dp, dp]
         L.orc_icp_config_default.argtypes = [C.POINTER(Config)]
@@ -178,6 +180,27 @@ def voxel_downsample(points, voxel_size):
     out = np.empty_like(p)
     c = lib().orc_voxel_downsample(pp, p.shape[0], float(voxel_size), out.ctypes.data_as(C.POINTER(C.c_double)))
     return out[:c].copy()
+
+
+GRID_DEFAULTS = dict(resolution=0.2, height_min=0.3, height_max=2.0, max_range=40.0)   # slam_node.hpp:35-40
+
+
+def occupancy_cells(world, sensor, resolution=0.2, height_min=0.3, height_max=2.0, max_range=40.0):
+    """update_occupancy_grid (slam_node.cpp:211-221): (cells int32 n x 2, keep bool n) per world point."""
+    p, pp = _d(world)
+    sx, sp = _d(np.asarray(sensor, dtype=np.float64).reshape(3))
+    cells = np.zeros((p.shape[0], 2), dtype=np.int32)
+    keep = np.zeros(p.shape[0], dtype=np.uint8)
+    lib().orc_occupancy_cells(pp, p.shape[0], sp, float(resolution), float(height_min), float(height_max), float(max_range),
+                              cells.ctypes.data_as(C.POINTER(C.c_int)), keep.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return cells, keep.astype(bool)
+
+
+def occupancy_update(cell_set, world, sensor, **grid):
+    """occupied_cells_.insert(...) for every kept point: `cell_set` is a Python set of (x, y), updated in place."""
+    cells, keep = occupancy_cells(world, sensor, **grid)
+    cell_set.update(map(tuple, cells[keep].tolist()))
+    return cell_set
 
 
 def scan_context(cloud):
