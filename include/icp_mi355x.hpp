@@ -13,6 +13,11 @@
 //   slam::estimate_normals      icp.hpp:23-67            estimate_normals
 //   slam::solve_point_to_plane  icp.hpp:89-144           solve_point_to_plane
 //   (north_star wording)                                 ICP::align
+//   SlamNode::process_frame, registration and map side   OdometryStream (push, map_update)
+//     (slam_viz/src/ros/slam_node.cpp:118-157)
+//   OccupancyGridConfig / GridCell / update_occupancy_grid / cells_to_occupancy_grid_msg
+//     (slam_viz/include/slam_viz/ros/slam_node.hpp:35-58, slam_node.cpp:211-221,279-297)
+//                                                        OccupancyGridConfig, GridCell, OccupancyGrid
 //
 // A caller that already has Eigen and the reference's own types uses
 // slam_icp_adapter.hpp instead, which keeps slam::icp_point_to_plane's exact signature.
@@ -335,6 +340,171 @@ inline Transformation solve_point_to_plane(const PointCloud &source, const Point
     if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(c.get()));
     return Transformation(T);
 }
+
+// ---- the caller's frame step (slam_viz/src/ros/slam_node.cpp:118-157) ---------------------------------
+struct OccupancyGridConfig { // slam_node.hpp:35-40
+    double resolution = 0.2;
+    double height_min = 0.3;
+    double height_max = 2.0;
+    double max_range = 40.0;
+};
+struct GridCell { // slam_node.hpp:45-50
+    int x, y;
+    bool operator==(const GridCell &o) const { return x == o.x && y == o.y; }
+};
+namespace detail {
+inline icpmi_grid_config to_c(const OccupancyGridConfig &g)
+{
+    icpmi_grid_config c;
+    c.resolution = g.resolution;
+    c.height_min = g.height_min;
+    c.height_max = g.height_max;
+    c.max_range = g.max_range;
+    return c;
+}
+} // namespace detail
+
+// occupied_cells_ and the functions around it (slam_node.cpp:211-226,279-297); the set lives in the
+// context's device memory, sorted by (x, y).
+class OccupancyGrid {
+public:
+    explicit OccupancyGrid(OccupancyGridConfig config = OccupancyGridConfig(), Context *ctx = nullptr)
+        : config_(config), ctx_(ctx ? ctx : &default_context())
+    {
+    }
+    // update_occupancy_grid(cloud, sensor) (slam_node.cpp:211-221) -> cells in the set afterwards
+    std::size_t update(const PointCloud &world, const std::array<double, 3> &sensor)
+    {
+        const icpmi_grid_config g = detail::to_c(config_);
+        int64_t n = 0;
+        const int rc = icpmi_occupancy_update(ctx_->get(), world.data(), static_cast<int64_t>(world.size()), sensor.data(), &g, &n);
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx_->get()));
+        return static_cast<std::size_t>(n);
+    }
+    void clear() { icpmi_occupancy_clear(ctx_->get()); } // slam_node.cpp:224
+    std::vector<GridCell> cells() const
+    {
+        int64_t n = 0;
+        int rc = icpmi_occupancy_cells(ctx_->get(), nullptr, 0, &n);
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx_->get()));
+        std::vector<GridCell> out(static_cast<std::size_t>(n));
+        static_assert(sizeof(GridCell) == 2 * sizeof(int32_t), "cells are read as int32 pairs");
+        if (n > 0) {
+            rc = icpmi_occupancy_cells(ctx_->get(), reinterpret_cast<int32_t *>(out.data()), n, &n);
+            if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx_->get()));
+        }
+        return out;
+    }
+    // cells_to_occupancy_grid_msg (slam_node.cpp:279-297) without the ROS message around it
+    struct Raster {
+        double resolution = 0.0, origin_x = 0.0, origin_y = 0.0;
+        int width = 0, height = 0;
+        std::vector<int8_t> data; // row-major [y][x], 100 = occupied
+    };
+    Raster raster() const
+    {
+        Raster r;
+        const std::vector<GridCell> c = cells();
+        if (c.empty()) return r;                                  // :283
+        int minx = c[0].x, maxx = c[0].x, miny = c[0].y, maxy = c[0].y;
+        for (const GridCell &k : c) {                             // :285
+            minx = k.x < minx ? k.x : minx;
+            maxx = k.x > maxx ? k.x : maxx;
+            miny = k.y < miny ? k.y : miny;
+            maxy = k.y > maxy ? k.y : maxy;
+        }
+        minx -= 5, miny -= 5, maxx += 5, maxy += 5;               // :286
+        r.width = maxx - minx + 1;
+        r.height = maxy - miny + 1;
+        r.resolution = config_.resolution;
+        r.origin_x = minx * config_.resolution;                   // :291-292
+        r.origin_y = miny * config_.resolution;
+        r.data.assign(static_cast<std::size_t>(r.width) * static_cast<std::size_t>(r.height), 0);
+        for (const GridCell &k : c) r.data[static_cast<std::size_t>(k.y - miny) * r.width + (k.x - minx)] = 100; // :295
+        return r;
+    }
+    const OccupancyGridConfig &config() const { return config_; }
+
+private:
+    OccupancyGridConfig config_;
+    Context *ctx_;
+};
+
+// process_frame as two calls per frame with the scans resident in device memory: push() is
+// lines 122-138 (voxel filter, guards, registration against the previous filtered scan), the caller
+// applies its gate and pose update (139-145), map_update() is lines 147-153 (world points of the
+// scan just pushed, occupancy insert with the new pose's translation as the sensor position).
+class OdometryStream {
+public:
+    explicit OdometryStream(Context *ctx = nullptr) : ctx_(ctx ? ctx : &default_context()) {}
+    struct Step {
+        ICPResult result;            // identity / converged = false unless `registered`
+        bool registered = false;     // an ICP ran (source = this scan, target = the previous one)
+        bool first_frame = false;    // slam_node.cpp:69-72
+        bool too_few_points = false; // slam_node.cpp:125-130
+        std::size_t filtered_points = 0;
+    };
+    Step push(const PointCloud &raw, double voxel_size, long long min_points, const ICPConfig &config = ICPConfig())
+    {
+        icpmi_config k = detail::to_c(config);
+        std::vector<double> hist(static_cast<std::size_t>(config.max_iterations > 0 ? config.max_iterations : 0) + 1);
+        icpmi_result out;
+        icpmi_stream_info info;
+        const int rc = icpmi_stream_push_host(ctx_->get(), raw.data(), static_cast<int64_t>(raw.size()), voxel_size, min_points, &k,
+                                              &out, hist.data(), static_cast<int32_t>(hist.size()), &info);
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx_->get()));
+        return finish(out, info, std::move(hist));
+    }
+    // the scan as a file (load_ply / load_bin, slam_node.cpp:121)
+    Step push_file(const std::string &path, double voxel_size, long long min_points, const ICPConfig &config = ICPConfig())
+    {
+        icpmi_config k = detail::to_c(config);
+        std::vector<double> hist(static_cast<std::size_t>(config.max_iterations > 0 ? config.max_iterations : 0) + 1);
+        icpmi_result out;
+        icpmi_stream_info info;
+        const int rc = icpmi_stream_push_file(ctx_->get(), path.c_str(), voxel_size, min_points, &k, &out, hist.data(),
+                                              static_cast<int32_t>(hist.size()), &info);
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx_->get()));
+        return finish(out, info, std::move(hist));
+    }
+    // world = curr * R^T + t^T (:147) of the scan just pushed; with `grid`, update_occupancy_grid(world, t) (:153)
+    // into the context's cell set (read it through OccupancyGrid::cells / raster on the same context)
+    PointCloud map_update(const Transformation &new_pose, const OccupancyGridConfig *grid = nullptr, std::size_t *n_cells = nullptr)
+    {
+        int64_t nw = static_cast<int64_t>(last_filtered_), nc = 0;
+        std::vector<double> world(3 * last_filtered_);
+        icpmi_grid_config g;
+        if (grid) g = detail::to_c(*grid);
+        const int rc = icpmi_stream_map_update(ctx_->get(), new_pose.matrix().data(), grid ? &g : nullptr, world.data(), nw, &nw, &nc);
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx_->get()));
+        if (n_cells) *n_cells = static_cast<std::size_t>(nc);
+        return PointCloud(std::move(world));
+    }
+    void reset() { icpmi_stream_reset(ctx_->get()); }
+
+private:
+    Step finish(const icpmi_result &out, const icpmi_stream_info &info, std::vector<double> hist)
+    {
+        Step step;
+        step.filtered_points = last_filtered_ = static_cast<std::size_t>(info.n_filtered);
+        step.first_frame = info.status == ICPMI_STREAM_FIRST_FRAME;
+        step.too_few_points = info.status == ICPMI_STREAM_TOO_FEW_POINTS;
+        step.registered = info.status == ICPMI_STREAM_REGISTERED;
+        if (step.registered) {
+            std::array<double, 16> m;
+            for (int i = 0; i < 16; ++i) m[i] = out.transformation[i];
+            step.result.transformation = Transformation(m);
+            step.result.converged = out.converged != 0;
+            step.result.num_iterations = out.num_iterations;
+            step.result.final_error = out.final_error;
+            hist.resize(static_cast<std::size_t>(out.history_len));
+            step.result.error_history = std::move(hist);
+        }
+        return step;
+    }
+    Context *ctx_;
+    std::size_t last_filtered_ = 0;
+};
 
 // `ICP(config).align(source, target)`: the facade BASELINE.json's north_star names.
 class ICP {

@@ -24,6 +24,7 @@
 // <Eigen/Dense> and a reference checkout exist (tests/test_boundary.py).
 #pragma once
 
+#include <utility>
 #include <vector>
 
 #include "slam_viz/core/types.hpp"
@@ -136,7 +137,7 @@ struct OdometryStream {
         if (icpmi_stream_push_host(ctx, raw.data(), static_cast<int64_t>(raw.rows()), voxel_size, min_points, &k, &out,
                                    hist.data(), static_cast<int32_t>(hist.size()), &info) != ICPMI_OK)
             return step;
-        step.filtered_points = info.n_filtered;
+        step.filtered_points = last_filtered_ = info.n_filtered;
         step.first_frame = info.status == ICPMI_STREAM_FIRST_FRAME;
         step.too_few_points = info.status == ICPMI_STREAM_TOO_FEW_POINTS;
         step.registered = info.status == ICPMI_STREAM_REGISTERED;
@@ -152,7 +153,50 @@ struct OdometryStream {
         }
         return step;
     }
-    void reset() { if (icpmi_ctx *ctx = icp_mi355x_detail::context()) icpmi_stream_reset(ctx); }
+    // The map side of process_frame (slam_node.cpp:147-153) for the scan just pushed, which never came to the
+    // host: returns world = curr * new_pose.R()^T + new_pose.t()^T (what :147 computes and :155 publishes) and,
+    // with `grid` (the node's grid_config_ fields), does update_occupancy_grid(world, new_pose.t()) on the
+    // device-resident cell set.  In process_frame, in place of lines 147 and 153:
+    //     auto world = stream_.map_update(new_pose, &grid_);   // grid_ = {resolution, height_min, height_max, max_range}
+    // and cells_to_occupancy_grid_msg (:279-297) iterates stream_.occupied_cells() instead of occupied_cells_.
+    PointCloud::Matrix map_update(const Transformation &new_pose, const icpmi_grid_config *grid = nullptr)
+    {
+        icpmi_ctx *ctx = icp_mi355x_detail::context();
+        if (!ctx || last_filtered_ <= 0) return PointCloud::Matrix(0, 3);
+        double T[16];
+        const auto &M = new_pose.matrix();
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) T[4 * r + c] = M(r, c);
+        PointCloud::Matrix world(last_filtered_, 3);
+        int64_t nw = 0, nc = 0;
+        if (icpmi_stream_map_update(ctx, T, grid, world.data(), static_cast<int64_t>(world.rows()), &nw, &nc) != ICPMI_OK)
+            return PointCloud::Matrix(0, 3);
+        return world;
+    }
+    // the occupied cells as (x, y) pairs, sorted by x then y (occupied_cells_, slam_node.hpp:151)
+    std::vector<std::pair<int, int>> occupied_cells() const
+    {
+        std::vector<std::pair<int, int>> out;
+        icpmi_ctx *ctx = icp_mi355x_detail::context();
+        int64_t n = 0;
+        if (!ctx || icpmi_occupancy_cells(ctx, nullptr, 0, &n) != ICPMI_OK || n <= 0) return out;
+        std::vector<int32_t> xy(2 * static_cast<size_t>(n));
+        if (icpmi_occupancy_cells(ctx, xy.data(), n, &n) != ICPMI_OK) return out;
+        out.reserve(static_cast<size_t>(n));
+        for (int64_t i = 0; i < n; ++i) out.emplace_back(xy[2 * i], xy[2 * i + 1]);
+        return out;
+    }
+    void reset()
+    {
+        if (icpmi_ctx *ctx = icp_mi355x_detail::context()) {
+            icpmi_stream_reset(ctx);
+            icpmi_occupancy_clear(ctx);
+        }
+        last_filtered_ = 0;
+    }
+
+private:
+    long long last_filtered_ = 0;
 };
 
 // The facade named in BASELINE.json's north_star.

@@ -128,20 +128,33 @@ def run_odometry_device(raw_frames, ctx, voxel=0.5, max_iterations=50, tolerance
     return track
 
 
-def run_odometry_stream(paths, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6, min_points=1000):
+def run_odometry_stream(paths, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6, min_points=1000, grid=None,
+                        want_world=False):
     """The same loop over frame FILES with everything but the file read on the device: one
     `icpmi_stream_push_file` per frame does slam_node.cpp:121-152 -- the scan goes from disk through
     pinned memory to HBM (`.bin`: float32 records, widened there), voxel filter, min-points guard,
     registration against the previous filtered scan that stayed resident -- and this function
-    applies the reference's gate and pose update (slam_node.cpp:139-142).  No torch in here."""
+    applies the reference's gate and pose update (slam_node.cpp:139-142).  With `grid` (a
+    capi.GridConfig) every frame also gets the map side (slam_node.cpp:147-153, `icpmi_stream_map_update`):
+    world points of the resident scan (copied out only with `want_world`) and the occupancy insert;
+    track.cells then holds the size of the cell set after each frame.  No torch in here."""
     from . import capi
     track = OdometryTrack()
+    track.cells = []
     cfg = capi.Context.make_config(max_iterations=max_iterations, tolerance=tolerance)
     ctx.stream_reset()
+    if grid is not None:
+        ctx.occupancy_clear()
+
+    def map_side():
+        if grid is not None:                                      # slam_node.cpp:147-153
+            _w, n_cells = ctx.stream_map_update(track.poses[-1], grid, want_world=want_world)
+            track.cells.append(n_cells)
+
     for k, path in enumerate(paths):
         t0 = time.perf_counter()
         res, _hist, info = ctx.stream_push_file(path, voxel, min_points, cfg)
-        if info.status == capi.STREAM_FIRST_FRAME:
+        if info.status == capi.STREAM_FIRST_FRAME:                # slam_node.cpp:69-72: kept, not inserted into the grid
             continue
         if info.status == capi.STREAM_TOO_FEW_POINTS:            # slam_node.cpp:125-130
             track.poses.append(track.poses[-1].copy())
@@ -150,7 +163,7 @@ def run_odometry_stream(paths, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6
             track.iterations.append(0)
             track.converged.append(False)
             track.gated.append(True)
-            track.frame_ms.append(1e3 * (time.perf_counter() - t0))
+            track.frame_ms.append(1e3 * (time.perf_counter() - t0))   # (the reference returns before its map update here)
             continue
         bad = (not res.converged) or res.final_error > 1.0        # slam_node.cpp:139-140
         delta = np.eye(4) if bad else np.array(res.transformation[:]).reshape(4, 4)
@@ -160,6 +173,7 @@ def run_odometry_stream(paths, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6
         track.iterations.append(res.num_iterations)
         track.converged.append(bool(res.converged))
         track.gated.append(bool(bad))
+        map_side()
         track.frame_ms.append(1e3 * (time.perf_counter() - t0))
     return track
 

@@ -14,8 +14,9 @@ def newest(pattern):
     return c[-1]
 
 for f in ("bench.json", "bench_20.json", "bench_extra.json", "engines_100k.json", "engines_1m.json", "engines_lidar_raw.json",
-          "event_overhead.txt", "sequence_200.json", "summary.txt", "ab_r1_r2.json", "threshold_sweep.json"):
-    if os.path.exists(os.path.join(F, f)):
+          "event_overhead.txt", "sequence_200.json", "sequence_200_map.json", "summary.txt", "ab_r1_r2.json", "threshold_sweep.json",
+          "ab_fuse_finish.json", "coarse_clock.json"):
+    if os.path.exists(os.path.join(F, f)) and os.path.getsize(os.path.join(F, f)) > 0:
         shutil.copy(os.path.join(F, f), os.path.join(P, f))
 shutil.copy(newest(F + "/stats/**/*kernel_stats.csv"), P + "/kernel_stats.csv")
 for g in ("fetch_size", "write_size", "grbm_gui_active", "sq_insts_valu", "sq_waves"):
@@ -38,4 +39,8 @@ print({k: q[k] for k in ("gpu_ms_per_frame_file_to_pose", "gpu_frame_ms_median",
 q = json.load(open(os.path.join(P, "small", "sequence_40.json")))
 print({k: q[k] for k in ("gpu_ms_per_frame_file_to_pose", "gpu_frame_ms_median", "iterations_total")})
 print(json.dumps(json.load(open(os.path.join(P, "ab_r1_r2.json")))))
+q = json.load(open(os.path.join(P, "sequence_200_map.json")))
+print({k: q[k] for k in ("gpu_ms_per_frame_file_to_pose", "gpu_frame_ms_median")}, q["map"]["occupied_cells"], q["oracle"].get("cell_sets_equal"))
+print(json.dumps(json.load(open(os.path.join(P, "ab_fuse_finish.json")))["summary_min_over_legs"]))
+print(open(os.path.join(P, "coarse_clock.json")).read())
 print(json.dumps(json.load(open(os.path.join(P, "bench_extra.json"))))[:1400])

@@ -23,6 +23,13 @@ timeout -k 10 300 python scripts/engine_compare_lidar.py > "$O/engines_lidar_raw
 timeout -k 10 100 python scripts/event_overhead.py > "$O/event_overhead.txt" 2>&1 || exit 1
 # C5 at stream length: 200 synthetic frames as KITTI .bin, file -> pose, with the oracle loop beside it
 timeout -k 10 600 python scripts/run_sequence.py --make-synthetic /tmp/drive200 --frames 0:200 --oracle > "$O/sequence_200.json" 2> "$O/sequence_200.err" || exit 1
+# ... and with the map side of every frame (world points + occupancy grid), the cell set compared with the oracle's
+timeout -k 10 600 python scripts/run_sequence.py --data_dir /tmp/drive200 --frames 0:200 --oracle --map > "$O/sequence_200_map.json" 2> "$O/sequence_200_map.err" || exit 1
+# same-box A/B of the fused finish + step + transform kernel, and the clock inside the coarse kernel
+timeout -k 10 300 python scripts/ab_fuse_finish.py > "$O/ab_fuse_finish.json" 2> "$O/ab_fuse_finish.err" || exit 1
+timeout -k 10 300 python scripts/coarse_clock.py 100000 3 > "$O/coarse_clock.json" 2> "$O/coarse_clock.err" || exit 1
+timeout -k 10 300 python scripts/ab_r1_r2.py > "$O/ab_r1_r2.json" 2> "$O/ab_r1_r2.err" || true   # needs scripts/ab_r1_libicp.so (round 1's library, built from git archive 0fd41fd)
+timeout -k 10 300 python scripts/threshold_sweep.py > "$O/threshold_sweep.json" 2> "$O/threshold_sweep.err" || exit 1
 # the small-cloud regime: kernel time against wall per frame
 mkdir -p "$O/small"
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/small/stats" -- python3 "$GRAFT_REPO_ROOT/scripts/run_sequence.py" --data_dir /tmp/drive200 --frames 0:40 > "$O/small/sequence_40_under_rocprof.json" 2> "$O/small/stats.err") || exit 1

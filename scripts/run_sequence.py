@@ -55,6 +55,10 @@ def main():
     ap.add_argument("--beams", type=int, default=64)
     ap.add_argument("--azimuths", type=int, default=1800)
     ap.add_argument("--oracle", action="store_true", help="also run the CPU oracle loop on the same frames (slow)")
+    ap.add_argument("--map", action="store_true",
+                    help="per frame also the map side of process_frame (slam_node.cpp:147-153): world points of the resident scan "
+                         "and the occupancy-grid insert, on the device; with --oracle the cell set is compared with the oracle's")
+    ap.add_argument("--world-out", action="store_true", help="with --map: copy every frame's world points to the host (what :155 publishes)")
     args = ap.parse_args()
     lo, hi = 0, None
     if args.frames:
@@ -80,9 +84,12 @@ def main():
     if truth is None and os.path.exists(tp):
         truth = list(np.load(tp))[lo:hi]
     ctx = capi.Context(device=0, search=args.search)
-    odometry.run_odometry_stream(paths[:3], ctx, args.voxel, args.max_iterations, args.tolerance, args.min_points)  # warm-up
+    grid = capi.Context.make_grid_config() if args.map else None                       # slam_node.hpp:35-40
+    odometry.run_odometry_stream(paths[:3], ctx, args.voxel, args.max_iterations, args.tolerance, args.min_points, grid,
+                                 args.world_out)  # warm-up
     t0 = time.perf_counter()
-    tr = odometry.run_odometry_stream(paths, ctx, args.voxel, args.max_iterations, args.tolerance, args.min_points)
+    tr = odometry.run_odometry_stream(paths, ctx, args.voxel, args.max_iterations, args.tolerance, args.min_points, grid,
+                                      args.world_out)
     wall = time.perf_counter() - t0
     out = {"data_dir": args.data_dir, "frames": len(paths), "first": frames[0][0], "last": frames[-1][0],
            "voxel": args.voxel, "max_iterations": args.max_iterations, "tolerance": args.tolerance,
@@ -96,6 +103,13 @@ def main():
                               for i in np.argsort(tr.frame_ms)[::-1][:8]]}
     if truth is not None:
         out["ate_gpu_m"] = odometry.absolute_trajectory_error(tr, truth)
+    gpu_cells = None
+    if args.map:
+        gpu_cells = ctx.occupancy_cells()
+        out["map"] = {"occupied_cells": int(gpu_cells.shape[0]), "world_points_copied_out": bool(args.world_out),
+                      "grid": {"resolution": grid.resolution, "height_min": grid.height_min, "height_max": grid.height_max,
+                               "max_range": grid.max_range},
+                      "note": "gpu_ms_per_frame_file_to_pose includes the map side of every frame"}
     if args.oracle:
         from oracle import oracle as orc
         nth = os.cpu_count() or 1
@@ -111,6 +125,21 @@ def main():
                          "max_pose_dt_m": float(max(np.linalg.norm(a[:3, 3] - b[:3, 3]) for a, b in zip(tr.poses, rf.poses)))}
         if truth is not None:
             out["oracle"]["ate_cpu_m"] = odometry.absolute_trajectory_error(rf, truth)
+        if args.map:
+            # update_occupancy_grid (slam_node.cpp:211-221) by the oracle over the oracle-filtered scans, moved by the
+            # GPU loop's poses (so that the comparison is of the map side alone); the first frame and the
+            # too-few-points frames take no part, as in the reference (:69-76, :125-130)
+            want = set()
+            for i, p in enumerate(paths):
+                curr = orc.voxel_downsample(capi.load_cloud(p), args.voxel)
+                if i == 0 or curr.shape[0] < args.min_points:
+                    continue
+                T = tr.poses[i]
+                R, t = T[:3, :3], T[:3, 3]
+                world = np.stack([((curr[:, 0] * R[a, 0] + curr[:, 1] * R[a, 1]) + curr[:, 2] * R[a, 2]) + t[a] for a in range(3)], axis=1)
+                orc.occupancy_update(want, world, t)
+            out["oracle"]["occupied_cells"] = len(want)
+            out["oracle"]["cell_sets_equal"] = want == set(map(tuple, gpu_cells.tolist()))
     print(json.dumps(out, indent=1))
     ctx.close()
     return 0

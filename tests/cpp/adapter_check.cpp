@@ -15,7 +15,12 @@ int main()
     slam::OdometryStream stream;
     slam::OdometryStream::Step s = stream.push(a.points(), 0.5, 1000, cfg);
     slam::PointCloud::Matrix v = slam::voxel_downsample_mi355x(a.points(), 0.5);
-    return (r.converged || s.registered || v.rows() > 0) ? 1 : 0;
+    icpmi_grid_config grid;
+    icpmi_grid_config_default(&grid);
+    slam::PointCloud::Matrix world = stream.map_update(slam::Transformation::identity(), &grid);
+    std::vector<std::pair<int, int>> cells = stream.occupied_cells();
+    stream.reset();
+    return (r.converged || s.registered || v.rows() > 0 || world.rows() > 0 || !cells.empty()) ? 1 : 0;
 }
 #else
 #error "adapter_check: <Eigen/Dense> or slam_viz/core/types.hpp not found -- nothing to check here"

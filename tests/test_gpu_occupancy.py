@@ -120,3 +120,49 @@ def test_stream_map_update_is_the_map_side_of_process_frame(tmp_path, oracle):
     with pytest.raises(capi.IcpError):
         ctx.stream_map_update(pose, grid)
     ctx.close()
+
+
+def test_cpp_stream_mirror(tmp_path):
+    """include/icp_mi355x.hpp's OdometryStream + OccupancyGrid from a plain C++17 program
+    (tests/cpp/stream_demo.cpp) against the same loop driven from Python through the same C ABI:
+    statuses, iteration counts, poses, world-point checksums, the cell set and its raster must agree exactly."""
+    import subprocess
+    import run_sequence
+    from lidar_slam_from_scratch_amd import build
+    run_sequence.write_synthetic_drive(str(tmp_path), 0, 8, beams=32, azimuths=900)
+    paths = [p for _, p in capi.discover_frames(str(tmp_path))]
+    exe = tmp_path / "stream_demo"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "stream_demo.cpp"), "-o", str(exe), build.LIB_PATH,
+                           "-Wl,-rpath," + os.path.dirname(build.LIB_PATH), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
+                           "-lamdhip64"])
+    subprocess.check_call([str(exe), str(tmp_path / "o.f64")] + paths)
+    o = np.fromfile(tmp_path / "o.f64")
+    assert int(o[0]) == len(paths)
+    ctx = capi.Context(device=0)
+    cfg, grid = capi.Context.make_config(), capi.Context.make_grid_config()
+    pose = np.eye(4)
+    p = 1
+    for path in paths:
+        res, _, info = ctx.stream_push_file(path, 0.5, 1000, cfg)
+        if info.status == capi.STREAM_REGISTERED:
+            T = np.array(res.transformation[:]).reshape(4, 4)
+            pose = pose @ (np.eye(4) if (not res.converged or res.final_error > 1.0) else T)
+        world, n_cells = ctx.stream_map_update(pose, grid)
+        status, iters, nf, nc = o[p:p + 4]
+        assert (int(status), int(nf), int(nc)) == (info.status, info.n_filtered, n_cells)
+        assert int(iters) == (res.num_iterations if info.status == capi.STREAM_REGISTERED else 0)
+        cpose = o[p + 4:p + 20].reshape(4, 4)
+        # the C++ 4x4 product adds in index order like numpy's matmul may not: compare to rounding
+        np.testing.assert_allclose(cpose, pose, rtol=0, atol=1e-13)
+        pose = cpose                                   # keep both loops on the same pose from here on
+        assert abs(o[p + 20] - world.sum()) <= 1e-6 * max(1.0, abs(world).sum())
+        p += 21
+    cells = ctx.occupancy_cells()
+    n = int(o[p]); p += 1
+    assert n == cells.shape[0] and (o[p:p + 2 * n].reshape(n, 2) == cells).all()
+    p += 2 * n
+    w, h, ox, oy, occ = o[p:p + 5]
+    assert int(w) == cells[:, 0].max() - cells[:, 0].min() + 11 and int(h) == cells[:, 1].max() - cells[:, 1].min() + 11
+    assert ox == (cells[:, 0].min() - 5) * 0.2 and oy == (cells[:, 1].min() - 5) * 0.2 and int(occ) == n
+    ctx.close()
