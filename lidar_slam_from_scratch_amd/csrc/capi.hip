@@ -347,7 +347,7 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     const int ms = (m + 63) / 64 * 64; // component stride of the SoA sorted copy
     ctx->nn_ms = ms;
     if ((rc = reserve(ctx, ctx->tgt_sorted, sizeof(double) * 3 * (size_t)ms))) return rc;
-    if ((rc = reserve(ctx, ctx->frames, sizeof(SplitFrame) * (size_t)splits))) return rc;
+    if ((rc = reserve(ctx, ctx->frames, frames_bytes(splits)))) return rc; // split frames, then the slots' boxes
     NnFrame *frame = (NnFrame *)ctx->nn_misc.p;
     unsigned *keys_in = (unsigned *)ctx->sort_keys.p, *keys_out = keys_in + m, *vals_in = keys_in + 2 * (size_t)m,
              *perm = keys_in + 3 * (size_t)m;

@@ -30,7 +30,8 @@
 // Resolve (k_nn_resolve / k_knn_resolve), fp64 in the reference's operation order: exact
 // scan of the winning slot -> D; every target with exact distance <= D has a coarse value
 // <= tau_s = D + E_s(D) in its split s, so every slot whose recorded minimum is under its
-// split's tau_s is scanned exactly too.  Result: exact minimum, ties to the lowest ORIGINAL
+// split's tau_s is scanned exactly too (a split whose SECOND minimum is under it as a whole:
+// scan_split, the slots culled by their bounding boxes).  Result: exact minimum, ties to the lowest ORIGINAL
 // index -- bit-identical to k_nn_f64 and to the oracle.
 //
 // Error bound E_s(d) for a pair in split s.  a >= |p-c_s| + rho_s, u = 2^-24.
@@ -225,23 +226,49 @@ __global__ __launch_bounds__(256) void k_gather_points(const double *__restrict_
     ICPMI_SZ(out, ms, i) = pts[3 * j + 2];
 }
 
-// one workgroup per split: bounding box of its sorted points -> centre and radius
+// one workgroup per split: bounding box of its sorted points -> centre and radius; and, behind the
+// frames, the bounding box of each of its 32 SLOTS (64 targets contiguous in the sorted array:
+// a compact blob), six doubles per slot, which let the resolve cull a whole-split scan down to the
+// few slots that can hold a target within the current distance (scan_split).  An empty slot keeps
+// lo = +1.7e308 > hi = -1.7e308: infinitely far from every query.
+constexpr bool kSlotBoxes = kSlotTargets == 64; // one wave-wide load per slot; other slot sizes scan whole splits
+__host__ __device__ inline size_t frames_bytes(int splits)
+{
+    return sizeof(SplitFrame) * (size_t)splits + (kSlotBoxes ? sizeof(double) * 6 * kCols * (size_t)splits : 0);
+}
 __global__ __launch_bounds__(256) void k_split_frames(const double *__restrict__ sorted, int m, int ms,
                                                       SplitFrame *__restrict__ frames)
 {
     const int s = blockIdx.x;
     const int j0 = s * kSplitTargets, j1 = min(m, j0 + kSplitTargets);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *slot_boxes = reinterpret_cast<double *>(frames + gridDim.x);
     double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
-    for (int j = j0 + threadIdx.x; j < j1; j += 256) {
-        if (!finite3(ICPMI_SX(sorted, ms, j), ICPMI_SY(sorted, ms, j), ICPMI_SZ(sorted, ms, j))) continue;
+    for (int k = 0; k < kSplitTargets / 256; ++k) { // wave `wave` of round k holds slot 4 k + wave (when a slot is 64 targets)
+        const int j = j0 + threadIdx.x + 256 * k;
+        const bool ok = j < j1 && finite3(ICPMI_SX(sorted, ms, j), ICPMI_SY(sorted, ms, j), ICPMI_SZ(sorted, ms, j));
+        double bl[3], bh[3];
         for (int a = 0; a < 3; ++a) {
-            const double v = sorted[(size_t)a * ms + j];
-            lo[a] = v < lo[a] ? v : lo[a];
-            hi[a] = v > hi[a] ? v : hi[a];
+            const double v = ok ? sorted[(size_t)a * ms + j] : 0.0;
+            bl[a] = ok ? v : 1.7e308;
+            bh[a] = ok ? v : -1.7e308;
+            lo[a] = bl[a] < lo[a] ? bl[a] : lo[a];
+            hi[a] = bh[a] > hi[a] ? bh[a] : hi[a];
+        }
+        if (kSlotBoxes) {
+            for (int a = 0; a < 3; ++a)
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double l2 = __shfl_xor(bl[a], off, 64), h2 = __shfl_xor(bh[a], off, 64);
+                    bl[a] = l2 < bl[a] ? l2 : bl[a];
+                    bh[a] = h2 > bh[a] ? h2 : bh[a];
+                }
+            if (lane < 6) { // (selects, not a run-time index into the arrays: that would put them in scratch)
+                const double v = lane == 0 ? bl[0] : lane == 1 ? bl[1] : lane == 2 ? bl[2] : lane == 3 ? bh[0] : lane == 4 ? bh[1] : bh[2];
+                slot_boxes[((size_t)s * kCols + 4 * k + wave) * 6 + lane] = v;
+            }
         }
     }
     __shared__ double red[4][6];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int a = 0; a < 3; ++a) {
         double l = lo[a], h = hi[a];
         for (int off = 32; off > 0; off >>= 1) {
@@ -927,22 +954,99 @@ __device__ __forceinline__ void wave_argmin(double &d, int &j)
     }
 }
 
-// exact scan of sorted positions [j0, j0+len) for the query (px,py,pz), all lanes cooperate;
-// (bd, bj) is updated with the smaller (distance, ORIGINAL index)
+// exact scan of sorted positions [j0, j0+LEN) for the query (px,py,pz), all lanes cooperate;
+// (bd, bj) is updated with the smaller (distance, ORIGINAL index).  The loads of up to MAXBATCH
+// rounds are in flight together (7 registers per round: the caller says what it can afford;
+// clamped addresses, the bound applied to the comparison only): a
+// whole split is 32 rounds, and as a chain of 32 dependent round trips one such scan was the tail
+// of the whole resolve kernel on LiDAR frames (a few dozen queries per pass need one).
+template <int LEN, int MAXBATCH>
 __device__ __forceinline__ void scan_range(const double *__restrict__ sorted,
-                                           const unsigned *__restrict__ perm, int m, int ms, int j0, int len,
+                                           const unsigned *__restrict__ perm, int m, int ms, int j0,
                                            double px, double py, double pz, int lane, double &bd, int &bj)
 {
+    static_assert(LEN % 64 == 0, "whole rounds of the wave");
+    constexpr int ROUNDS = LEN / 64, BATCH = ROUNDS < MAXBATCH ? ROUNDS : MAXBATCH;
     double d = 1.7976931348623157e308;
     int j = 0x7fffffff;
-    for (int o = lane; o < len; o += 64) {
-        const int jj = j0 + o;
-        if (jj < m) {
-            const double dd = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), px, py, pz);
-            const int oj = (int)perm[jj];
-            if (dd < d || (dd == d && oj < j)) {
+#pragma unroll 1
+    for (int r0 = 0; r0 < ROUNDS; r0 += BATCH) {
+        double x[BATCH], y[BATCH], z[BATCH];
+        int oj[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int jj = j0 + (r0 + u) * 64 + lane;
+            const int jc = jj < m ? jj : m - 1;
+            x[u] = ICPMI_SX(sorted, ms, jc), y[u] = ICPMI_SY(sorted, ms, jc), z[u] = ICPMI_SZ(sorted, ms, jc);
+            oj[u] = (int)perm[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int jj = j0 + (r0 + u) * 64 + lane;
+            const double dd = sqdist(x[u], y[u], z[u], px, py, pz);
+            if (jj < m && (dd < d || (dd == d && oj[u] < j))) {
                 d = dd;
-                j = oj;
+                j = oj[u];
+            }
+        }
+    }
+    wave_argmin(d, j);
+    if (d < bd || (d == bd && j < bj)) {
+        bd = d;
+        bj = j;
+    }
+}
+
+// exact scan of ALL of split sL for one query, by the whole wave, slots culled by their bounding
+// boxes: lane c < 32 forms the squared distance from the query to slot c's box (a lower bound of
+// the distance to every target in it; the factor 1 - 1e-9 covers this evaluation's own roundings)
+// and the slot is read only if that does not exceed `qbd`, the query's best distance so far --
+// a target at distance <= the final minimum <= qbd cannot sit in a culled slot, ties included.
+// Morton-contiguous slots are compact: 2-5 of 32 survive, and their loads go out MAXBATCH slots
+// at a time.  Without slot boxes (slot sizes other than 64) every slot is read.
+template <int MAXBATCH>
+__device__ __forceinline__ void scan_split(const double *__restrict__ sorted, const unsigned *__restrict__ perm,
+                                           int m, int ms, const double *__restrict__ slot_boxes, int sL,
+                                           double qx, double qy, double qz, double qbd, int lane, double &bd, int &bj)
+{
+    if (!kSlotBoxes) {
+        scan_range<kSplitTargets, MAXBATCH>(sorted, perm, m, ms, sL * kSplitTargets, qx, qy, qz, lane, bd, bj);
+        return;
+    }
+    bool keep = false;
+    if (lane < kCols) {
+        const double *b = slot_boxes + ((size_t)sL * kCols + lane) * 6;
+        double lb = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double q = px_sel(a, qx, qy, qz);
+            const double g1 = b[a] - q, g2 = q - b[3 + a];
+            const double g = g1 > g2 ? (g1 > 0.0 ? g1 : 0.0) : (g2 > 0.0 ? g2 : 0.0);
+            lb += g * g;
+        }
+        keep = !(lb * (1.0 - 1e-9) > qbd);
+    }
+    unsigned mask = (unsigned)__ballot(keep); // wave-uniform
+    double d = 1.7976931348623157e308;
+    int j = 0x7fffffff;
+    while (mask) {
+        double x[MAXBATCH], y[MAXBATCH], z[MAXBATCH];
+        int oj[MAXBATCH], jj[MAXBATCH];
+#pragma unroll
+        for (int u = 0; u < MAXBATCH; ++u) {
+            const int c = mask ? __ffs((int)mask) - 1 : -1;
+            mask &= mask - 1u; // (0 stays 0)
+            jj[u] = c >= 0 ? sL * kSplitTargets + c * kSlotTargets + lane : m;
+            const int jc = jj[u] < m ? jj[u] : m - 1;
+            x[u] = ICPMI_SX(sorted, ms, jc), y[u] = ICPMI_SY(sorted, ms, jc), z[u] = ICPMI_SZ(sorted, ms, jc);
+            oj[u] = (int)perm[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < MAXBATCH; ++u) {
+            const double dd = sqdist(x[u], y[u], z[u], qx, qy, qz);
+            if (jj[u] < m && (dd < d || (dd == d && oj[u] < j))) {
+                d = dd;
+                j = oj[u];
             }
         }
     }
@@ -960,7 +1064,7 @@ __device__ __forceinline__ void scan_range(const double *__restrict__ sorted,
 // survivors remembered as bits.  Only they -- the query's own split and the odd neighbour, 1-3
 // of 49 on the 100k cloud -- get the per-split bound (frame loads + ~40 fp64 operations), and
 // the slots or splits under it are scanned exactly by the whole wave.
-template <int GROUP, int Q, int KEEP>
+template <int GROUP, int Q, int KEEP, int SCANBATCH>
 __device__ __forceinline__ void resolve_certify(const float (&pv)[KEEP > 0 ? KEEP : 1], // phase 1's first KEEP values per lane
                                                 const int lane, const int sub, const bool valid, const int ic, const int n,
                                                 const double px, const double py, const double pz,
@@ -1016,6 +1120,11 @@ __device__ __forceinline__ void resolve_certify(const float (&pv)[KEEP > 0 ? KEE
                 whole = v.y <= tauf;                       // a second column is inside the bound
                 slot = !whole && s != bs && v.x <= tauf;
             }
+#if defined(ICPMI_TIMING_SKIP_SCANS) /* timing experiment only (WRONG results): 1 = no whole-split scans, 2 = nothing of the
+                                        certificate survives (its results are unused) */
+            if (ICPMI_TIMING_SKIP_SCANS >= 1) whole = false;
+            if (ICPMI_TIMING_SKIP_SCANS >= 2) slot = false;
+#endif
             unsigned long long pend = __ballot(whole || slot);
             while (pend) {                                 // rare; wave-uniform loop
                 const int L = __ffsll((long long)pend) - 1;
@@ -1026,8 +1135,10 @@ __device__ __forceinline__ void resolve_certify(const float (&pv)[KEEP > 0 ? KEE
                 const int sL = __shfl(s, L, 64);
                 double d = 1.7976931348623157e308;
                 int j = 0x7fffffff;
-                if (w) scan_range(sorted, perm, m, ms, sL * kSplitTargets, kSplitTargets, qx, qy, qz, lane, d, j);
-                else scan_range(sorted, perm, m, ms, sL * kSplitTargets + c * kSlotTargets, kSlotTargets, qx, qy, qz, lane, d, j);
+                if (w)
+                    scan_split<SCANBATCH>(sorted, perm, m, ms, reinterpret_cast<const double *>(frames + nsplits), sL, qx, qy, qz,
+                                          __shfl(bd, L, 64), lane, d, j);
+                else scan_range<kSlotTargets, 1>(sorted, perm, m, ms, sL * kSplitTargets + c * kSlotTargets, qx, qy, qz, lane, d, j);
                 // every lane that holds this query takes the result
                 // (Q queries per wave laid out as lane % Q, or one query per quarter-wave when Q == 4)
                 const bool mine = Q == 4 ? (lane >> 4) == (L >> 4) : (lane & (Q - 1)) == (L & (Q - 1));
@@ -1058,6 +1169,14 @@ constexpr int kResolveQ = 16;
 #endif
 #ifndef ICPMI_RESOLVE_KEEP
 #define ICPMI_RESOLVE_KEEP 16 /* phase-1 values per lane kept for the certificate (64 splits at 16 queries per wave) */
+#endif
+// slots of a whole-split scan whose loads are in flight together (scan_split): what each kernel's
+// register budget allows
+#ifndef ICPMI_RESOLVE_SCANBATCH
+#define ICPMI_RESOLVE_SCANBATCH 1
+#endif
+#ifndef ICPMI_RESOLVE4_SCANBATCH
+#define ICPMI_RESOLVE4_SCANBATCH 2
 #endif
 #ifndef ICPMI_RESOLVE_UNROLL
 #define ICPMI_RESOLVE_UNROLL 4
@@ -1197,7 +1316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
 
     // phase 3: certificate (resolve_certify)
     unsigned extra_slots = 0, extra_splits = 0;
-    resolve_certify<SUBS, Q, KEEP>(pv, lane, sub, valid, ic, n, px, py, pz, coarse, splits, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
+    resolve_certify<SUBS, Q, KEEP, ICPMI_RESOLVE_SCANBATCH>(pv, lane, sub, valid, ic, n, px, py, pz, coarse, splits, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                              bd, bj, extra_slots, extra_splits);
     if (valid && sub == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
@@ -1378,7 +1497,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
 
     // phase 3: certificate (resolve_certify)
     unsigned extra_slots = 0, extra_splits = 0;
-    resolve_certify<16, 4, KEEP4>(pv, lane, ql, valid, ic, n, px, py, pz, coarse, splits, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
+    resolve_certify<16, 4, KEEP4, ICPMI_RESOLVE4_SCANBATCH>(pv, lane, ql, valid, ic, n, px, py, pz, coarse, splits, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                         bd, bj, extra_slots, extra_splits);
     if (valid && ql == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
