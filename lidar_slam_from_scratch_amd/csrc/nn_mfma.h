@@ -1796,6 +1796,9 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
     const int nsplits = LISTED ? nact : (nslots + kCols - 1) / kCols; // (local) splits this row looks at
     static_assert(kSlotTargets <= kKnnCap, "the best slot's targets must fit the candidate list");
     int total = 0;
+#if defined(ICPMI_KNN_STOP) && ICPMI_KNN_STOP == 4
+    int nf_last = 0, attempts_run = 0;
+#endif
     for (int attempt = 0; attempt < 4; ++attempt) {
         const double sq = sqrt(T);
         for (int sp = lane; sp < nsplits && sp < kKnnMaxSplits; sp += 64)
@@ -1857,12 +1860,15 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             const bool cand = e < nloc && e != bslot && mine(gslot(e)) <= tall;
             if (__ballot(cand)) list_flagged(cand, e);
         }
+#if defined(ICPMI_KNN_STOP) && ICPMI_KNN_STOP == 4
+        nf_last = nf, attempts_run = attempt + 1;
+#endif
         const bool overflow = nf > kKnnFlagCap; // (only with a bound that rules nothing out)
         const int nfl = overflow ? kKnnFlagCap : nf;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-        for (int f0 = 0; f0 < nfl; f0 += kKnnBatch) {
-            constexpr int kRuns = kSlotTargets / 64;
+        for (int f0 = 0; f0 < nfl && total <= kKnnCap; f0 += kKnnBatch) { // (once the list is full the bound gets tightened from
+            constexpr int kRuns = kSlotTargets / 64;                        //  what it holds: scanning on would only count)
             double d[kKnnBatch][kRuns];
             int jj[kKnnBatch][kRuns];
 #pragma unroll
@@ -1900,27 +1906,28 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             break;
         }
         if (total <= kKnnCap) break;
-        // k-th smallest of the kKnnCap candidates held (all real targets): new bound
+        // New bound from the kKnnCap candidates held (all real targets): each lane takes the smallest
+        // of its four, the k-th smallest of those 64 values bounds the k-th nearest distance from above
+        // like bound (b) does (64 different targets).  (The exact k-th smallest of all 256 took a
+        // 256 x 256 comparison count: ~10 us in a wave that every other wave of the launch then waited
+        // for -- on a LiDAR-like frame a dozen rows in ten thousand come here.)
         __builtin_amdgcn_wave_barrier();
-        double tnew = kInf;
+        double lm = kInf;
         for (int e = lane; e < kKnnCap; e += 64) {
             const double d = cand_d[wave][e];
-            int r = 0;
-            for (int f = 0; f < kKnnCap; ++f) {
-                const double df = cand_d[wave][f];
-                r += (df < d || (df == d && f < e)) ? 1 : 0;
-            }
-            if (r == kk - 1) tnew = d;
+            lm = d < lm ? d : lm;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double o = __shfl_xor(tnew, off, 64);
-            tnew = o < tnew ? o : tnew;
-        }
+        const double tnew = __shfl(wave_sort_asc(lm, lane), kk - 1, 64);
         __builtin_amdgcn_wave_barrier();
         if (!(tnew < T)) break; // cannot tighten (e.g. hundreds of coincident points)
         T = tnew;
     }
+#if defined(ICPMI_KNN_STOP) && ICPMI_KNN_STOP == 4 /* diagnostic only: per row, the slots listed, the candidates found and T, in place of neighbours */
+    if (total >= 0) {
+        if (lane < k) knn_idx[(size_t)i * k + lane] = lane == 0 ? nf_last : lane == 1 ? total : lane == 2 ? attempts_run : 0;
+        return;
+    }
+#endif
 #if defined(ICPMI_KNN_STOP) && ICPMI_KNN_STOP == 3 /* timing experiment only: stop after collecting candidates */
     if (total >= 0) { if (lane == 0) knn_idx[(size_t)i * k] = total; return; }
 #endif

@@ -17,7 +17,7 @@ for flags in "$@"; do
     (cd /tmp && TMPDIR=/tmp timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/seq" -- python3 "$GRAFT_REPO_ROOT/scripts/run_sequence.py" --data_dir /tmp/drive_small > "$O/seq.json" 2> /dev/null) || exit 1
     (cd /tmp && TMPDIR=/tmp timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/c3" -- python3 "$GRAFT_REPO_ROOT/scripts/run_align_once.py" 2 > "$O/c3.log" 2>&1) || exit 1
     echo "=== $flags"
-    python scripts/prof_summary.py "$O/seq" | grep "k_nn_resolve4\|k_nn_coarse<0"
+    python scripts/prof_summary.py "$O/seq" | grep "k_nn_resolve4\|k_nn_coarse<0\|k_knn_resolve\|k_nn_coarse<1\|k_knn_exact\|k_normals"
     python scripts/prof_summary.py "$O/c3" | grep "k_nn_resolve<"
     python -c "import json; d=json.load(open('$O/seq.json')); print('   ms per frame %.3f median %.3f' % (d['gpu_ms_per_frame_file_to_pose'], d['gpu_frame_ms_median']))"
 done
