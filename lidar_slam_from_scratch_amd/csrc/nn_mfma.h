@@ -244,27 +244,40 @@ __global__ __launch_bounds__(256) void k_split_frames(const double *__restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *slot_boxes = reinterpret_cast<double *>(frames + gridDim.x);
     double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
-    for (int k = 0; k < kSplitTargets / 256; ++k) { // wave `wave` of round k holds slot 4 k + wave (when a slot is 64 targets)
-        const int j = j0 + threadIdx.x + 256 * k;
-        const bool ok = j < j1 && finite3(ICPMI_SX(sorted, ms, j), ICPMI_SY(sorted, ms, j), ICPMI_SZ(sorted, ms, j));
-        double bl[3], bh[3];
-        for (int a = 0; a < 3; ++a) {
-            const double v = ok ? sorted[(size_t)a * ms + j] : 0.0;
-            bl[a] = ok ? v : 1.7e308;
-            bh[a] = ok ? v : -1.7e308;
-            lo[a] = bl[a] < lo[a] ? bl[a] : lo[a];
-            hi[a] = bh[a] > hi[a] ? bh[a] : hi[a];
+    if (kSlotBoxes) {
+        // eight threads per slot: thread t takes targets (t % 8) + 8 i, i = 0..7, of slot t / 8 -- minima
+        // and maxima gather in registers and three exchange steps inside the group of eight finish
+        // a slot (a wave per slot needed six steps on six doubles for every 64 targets: 2.5x the time)
+        static_assert(!kSlotBoxes || kCols * 8 == 256, "eight threads per slot");
+        const int c = threadIdx.x >> 3, sub = threadIdx.x & 7;
+#pragma unroll
+        for (int i = 0; i < kSlotTargets / 8; ++i) {
+            const int j = j0 + c * kSlotTargets + sub + 8 * i;
+            const bool ok = j < j1 && finite3(ICPMI_SX(sorted, ms, j), ICPMI_SY(sorted, ms, j), ICPMI_SZ(sorted, ms, j));
+            for (int a = 0; a < 3; ++a) {
+                const double v = ok ? sorted[(size_t)a * ms + j] : 0.0;
+                lo[a] = ok && v < lo[a] ? v : lo[a];
+                hi[a] = ok && v > hi[a] ? v : hi[a];
+            }
         }
-        if (kSlotBoxes) {
-            for (int a = 0; a < 3; ++a)
-                for (int off = 32; off > 0; off >>= 1) {
-                    const double l2 = __shfl_xor(bl[a], off, 64), h2 = __shfl_xor(bh[a], off, 64);
-                    bl[a] = l2 < bl[a] ? l2 : bl[a];
-                    bh[a] = h2 > bh[a] ? h2 : bh[a];
-                }
-            if (lane < 6) { // (selects, not a run-time index into the arrays: that would put them in scratch)
-                const double v = lane == 0 ? bl[0] : lane == 1 ? bl[1] : lane == 2 ? bl[2] : lane == 3 ? bh[0] : lane == 4 ? bh[1] : bh[2];
-                slot_boxes[((size_t)s * kCols + 4 * k + wave) * 6 + lane] = v;
+        double bl[3] = {lo[0], lo[1], lo[2]}, bh[3] = {hi[0], hi[1], hi[2]};
+        for (int a = 0; a < 3; ++a)
+            for (int off = 4; off > 0; off >>= 1) {
+                const double l2 = __shfl_xor(bl[a], off, 64), h2 = __shfl_xor(bh[a], off, 64);
+                bl[a] = l2 < bl[a] ? l2 : bl[a];
+                bh[a] = h2 > bh[a] ? h2 : bh[a];
+            }
+        if (sub < 6) { // (selects, not a run-time index into the arrays: that would put them in scratch)
+            const double v = sub == 0 ? bl[0] : sub == 1 ? bl[1] : sub == 2 ? bl[2] : sub == 3 ? bh[0] : sub == 4 ? bh[1] : bh[2];
+            slot_boxes[((size_t)s * kCols + c) * 6 + sub] = v;
+        }
+    } else {
+        for (int j = j0 + threadIdx.x; j < j1; j += 256) {
+            if (!finite3(ICPMI_SX(sorted, ms, j), ICPMI_SY(sorted, ms, j), ICPMI_SZ(sorted, ms, j))) continue;
+            for (int a = 0; a < 3; ++a) {
+                const double v = sorted[(size_t)a * ms + j];
+                lo[a] = v < lo[a] ? v : lo[a];
+                hi[a] = v > hi[a] ? v : hi[a];
             }
         }
     }
