@@ -55,6 +55,14 @@ dc, dr = a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
 ok = dr > 0
 ghz = dc[ok] / dr[ok] * 0.1
 span_us = (a[:, 3].max() - a[:, 1].min()) / 100.0
+# the last pass as a timeline: units in flight per 10 us bin, and how long a unit takes by when it starts
+t0s = (a[:, 1] - a[:, 1].min()) / 100.0
+t1s = (a[:, 3] - a[:, 1].min()) / 100.0
+bins = np.arange(0.0, t1s.max() + 10.0, 10.0)
+in_flight = [int(((t0s < b + 10.0) & (t1s > b)).sum()) for b in bins]
+order = np.argsort(t0s)
+dec = np.array_split(order, 10)
+unit_us_by_start_decile = [round(float(np.median(t1s[i] - t0s[i])), 2) for i in dec]
 print(json.dumps({
     "points": n, "calls": calls, "ms_per_call": round(1e3 * wall / calls, 3), "units": int(units),
     "in_kernel_clock_GHz": {"median": round(float(np.median(ghz)), 3), "p10": round(float(np.percentile(ghz, 10)), 3),
@@ -63,5 +71,6 @@ print(json.dumps({
     "unit_cycles_median": int(np.median(dc[ok])),
     "cycles_per_mfma_at_4_waves_per_simd": round(float(np.median(dc[ok])) / (128 * 4), 1),
     "last_pass_first_stamp_to_last_us": round(float(span_us), 1),
+    "units_in_flight_per_10us_bin": in_flight, "unit_us_by_start_decile": unit_us_by_start_decile,
     "extra_flags": extra,
 }))
