@@ -467,6 +467,8 @@ public:
         if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx_->get()));
         return finish(out, info, std::move(hist));
     }
+    // start reading the NEXT frame's file on the context's worker thread; call before pushing the current frame
+    void prefetch_file(const std::string &path) { icpmi_stream_prefetch_file(ctx_->get(), path.c_str()); }
     // world = curr * R^T + t^T (:147) of the scan just pushed; with `grid`, update_occupancy_grid(world, t) (:153)
     // into the context's cell set (read it through OccupancyGrid::cells / raster on the same context)
     PointCloud map_update(const Transformation &new_pose, const OccupancyGridConfig *grid = nullptr, std::size_t *n_cells = nullptr)

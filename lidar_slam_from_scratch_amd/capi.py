@@ -24,7 +24,7 @@ EXPORTS = [
     "icpmi_comm_init_callbacks", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
     "icpmi_scan_context", "icpmi_scan_context_distances", "icpmi_load_cloud", "icpmi_load_cloud_device",
     "icpmi_upload_points_f32", "icpmi_discover_frames", "icpmi_estimate_normals_rows",
-    "icpmi_stream_push", "icpmi_stream_push_host", "icpmi_stream_push_file", "icpmi_stream_reset",
+    "icpmi_stream_push", "icpmi_stream_push_host", "icpmi_stream_push_file", "icpmi_stream_prefetch_file", "icpmi_stream_reset",
     "icpmi_grid_config_default", "icpmi_occupancy_update", "icpmi_occupancy_update_device", "icpmi_occupancy_cells",
     "icpmi_occupancy_clear", "icpmi_stream_map_update",
     "icpmi_reset_profile", "icpmi_get_profile",
@@ -172,6 +172,7 @@ def load_library(path=None):
     L.icpmi_stream_push_file.argtypes = [vp, C.c_char_p, C.c_double, C.c_int64, C.POINTER(Config), C.POINTER(Result), dp,
                                          C.c_int32, C.POINTER(StreamInfo)]
     L.icpmi_stream_reset.argtypes = [vp]
+    L.icpmi_stream_prefetch_file.argtypes = [vp, C.c_char_p]
     L.icpmi_grid_config_default.argtypes = [C.POINTER(GridConfig)]
     L.icpmi_grid_config_default.restype = None
     L.icpmi_occupancy_update.argtypes = [vp, dp, C.c_int64, dp, C.POINTER(GridConfig), i64p]
@@ -396,6 +397,10 @@ class Context:
         self._check(self._lib.icpmi_stream_push_file(self._h, os.fsencode(path), float(voxel), int(min_points),
                                                      C.byref(cfg), C.byref(res), _dp(hist), cap, C.byref(info)))
         return res, hist[:res.history_len].copy(), info
+
+    def stream_prefetch_file(self, path):
+        """start reading the NEXT frame file on the context's worker thread (call before pushing the current one)"""
+        self._check(self._lib.icpmi_stream_prefetch_file(self._h, os.fsencode(path)))
 
     def stream_reset(self):
         self._check(self._lib.icpmi_stream_reset(self._h))

@@ -129,7 +129,7 @@ def run_odometry_device(raw_frames, ctx, voxel=0.5, max_iterations=50, tolerance
 
 
 def run_odometry_stream(paths, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6, min_points=1000, grid=None,
-                        want_world=False):
+                        want_world=False, prefetch=True):
     """The same loop over frame FILES with everything but the file read on the device: one
     `icpmi_stream_push_file` per frame does slam_node.cpp:121-152 -- the scan goes from disk through
     pinned memory to HBM (`.bin`: float32 records, widened there), voxel filter, min-points guard,
@@ -137,7 +137,9 @@ def run_odometry_stream(paths, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6
     applies the reference's gate and pose update (slam_node.cpp:139-142).  With `grid` (a
     capi.GridConfig) every frame also gets the map side (slam_node.cpp:147-153, `icpmi_stream_map_update`):
     world points of the resident scan (copied out only with `want_world`) and the occupancy insert;
-    track.cells then holds the size of the cell set after each frame.  No torch in here."""
+    track.cells then holds the size of the cell set after each frame.  With `prefetch` the next
+    frame's file is read by the library's worker thread while this frame runs
+    (`icpmi_stream_prefetch_file`).  No torch in here."""
     from . import capi
     track = OdometryTrack()
     track.cells = []
@@ -151,8 +153,11 @@ def run_odometry_stream(paths, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6
             _w, n_cells = ctx.stream_map_update(track.poses[-1], grid, want_world=want_world)
             track.cells.append(n_cells)
 
+    paths = list(paths)
     for k, path in enumerate(paths):
         t0 = time.perf_counter()
+        if prefetch and k + 1 < len(paths):
+            ctx.stream_prefetch_file(paths[k + 1])                # read beside this frame's work
         res, _hist, info = ctx.stream_push_file(path, voxel, min_points, cfg)
         if info.status == capi.STREAM_FIRST_FRAME:                # slam_node.cpp:69-72: kept, not inserted into the grid
             continue

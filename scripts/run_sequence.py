@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--beams", type=int, default=64)
     ap.add_argument("--azimuths", type=int, default=1800)
     ap.add_argument("--oracle", action="store_true", help="also run the CPU oracle loop on the same frames (slow)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not read the next frame's file on the library's worker thread while the current frame runs")
     ap.add_argument("--map", action="store_true",
                     help="per frame also the map side of process_frame (slam_node.cpp:147-153): world points of the resident scan "
                          "and the occupancy-grid insert, on the device; with --oracle the cell set is compared with the oracle's")
@@ -86,13 +88,14 @@ def main():
     ctx = capi.Context(device=0, search=args.search)
     grid = capi.Context.make_grid_config() if args.map else None                       # slam_node.hpp:35-40
     odometry.run_odometry_stream(paths[:3], ctx, args.voxel, args.max_iterations, args.tolerance, args.min_points, grid,
-                                 args.world_out)  # warm-up
+                                 args.world_out, not args.no_prefetch)  # warm-up
     t0 = time.perf_counter()
     tr = odometry.run_odometry_stream(paths, ctx, args.voxel, args.max_iterations, args.tolerance, args.min_points, grid,
-                                      args.world_out)
+                                      args.world_out, not args.no_prefetch)
     wall = time.perf_counter() - t0
     out = {"data_dir": args.data_dir, "frames": len(paths), "first": frames[0][0], "last": frames[-1][0],
            "voxel": args.voxel, "max_iterations": args.max_iterations, "tolerance": args.tolerance,
+           "next_file_prefetched": not args.no_prefetch,
            "gpu_ms_per_frame_file_to_pose": 1e3 * wall / (len(paths) - 1),
            "gpu_frame_ms_median": float(np.median(tr.frame_ms)), "gpu_frame_ms_p95": float(np.percentile(tr.frame_ms, 95)),
            "iterations_total": int(sum(tr.iterations)), "iterations_per_frame_mean": float(np.mean(tr.iterations)),

@@ -29,6 +29,7 @@ int main(int argc, char **argv)
         im::Transformation pose;                                         // poses_[0] = identity (slam_node.cpp:73)
         std::vector<double> out{static_cast<double>(argc - 2)};
         for (int k = 2; k < argc; ++k) {
+            if (k + 1 < argc) stream.prefetch_file(argv[k + 1]);          // read beside this frame's work
             const im::OdometryStream::Step step = stream.push_file(argv[k], 0.5, 1000, cfg);
             if (step.registered) {
                 const bool gated = !step.result.converged || step.result.final_error > 1.0;      // :139-140

@@ -180,3 +180,35 @@ def test_c4_shard_properties(oracle):
     dt, dr = synth.pose_delta(np.array(res.transformation[:]).reshape(4, 4), ref.transformation)
     assert dt <= 1e-9 and dr <= 1e-9
     ctx.close()
+
+
+def test_prefetched_frames_give_the_same_stream(tmp_path):
+    """icpmi_stream_prefetch_file: the next frame's file read by the context's worker thread while the current
+    frame runs.  Same iteration counts, poses and errors as without; a prefetched path that is not the one
+    pushed next, a missing file and a PLY (no-op) must all leave the stream intact."""
+    import run_sequence
+    run_sequence.write_synthetic_drive(str(tmp_path), 0, 12, beams=32, azimuths=900)
+    paths = [p for _, p in capi.discover_frames(str(tmp_path))]
+    ctx = capi.Context(device=0)
+    a = odometry.run_odometry_stream(paths, ctx, prefetch=False)
+    b = odometry.run_odometry_stream(paths, ctx, prefetch=True)
+    assert a.iterations == b.iterations and a.gated == b.gated
+    assert all((x == y).all() for x, y in zip(a.poses, b.poses)) and a.final_errors == b.final_errors
+    cfg = capi.Context.make_config()
+    ctx.stream_reset()
+    ctx.stream_prefetch_file(paths[5])                       # not the one pushed next: the push reads its own file
+    _, _, i0 = ctx.stream_push_file(paths[0], 0.5, 1000, cfg)
+    r1, _, i1 = ctx.stream_push_file(paths[1], 0.5, 1000, cfg)
+    assert (i0.status, i1.status) == (capi.STREAM_FIRST_FRAME, capi.STREAM_REGISTERED) and r1.num_iterations == a.iterations[0]
+    ctx.stream_prefetch_file(str(tmp_path / "missing.bin"))  # cannot be read: reported by the push of that path only
+    r2, _, _ = ctx.stream_push_file(paths[2], 0.5, 1000, cfg)
+    assert r2.num_iterations == a.iterations[1]
+    with pytest.raises(capi.IcpError):
+        ctx.stream_push_file(str(tmp_path / "missing.bin"), 0.5, 1000, cfg)
+    ctx.stream_prefetch_file(str(tmp_path / "x.ply"))        # PLY: nothing to do ahead
+    ctx.stream_prefetch_file(paths[3])
+    ctx.stream_prefetch_file(paths[3])                       # twice: the second waits for the first
+    r3, _, _ = ctx.stream_push_file(paths[3], 0.5, 1000, cfg)
+    assert r3.num_iterations == a.iterations[2]
+    ctx.stream_prefetch_file(paths[4])                       # left pending: close() must stop the worker
+    ctx.close()
