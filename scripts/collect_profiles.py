@@ -14,7 +14,7 @@ def newest(pattern):
     return c[-1]
 
 for f in ("bench.json", "bench_20.json", "bench_extra.json", "engines_100k.json", "engines_1m.json", "engines_lidar_raw.json",
-          "event_overhead.txt", "sequence_200.json", "sequence_200_map.json", "summary.txt", "ab_r1_r2.json", "threshold_sweep.json",
+          "event_overhead.txt", "sequence_200.json", "sequence_200_noprefetch.json", "sequence_200_map.json", "summary.txt", "ab_r1_r2.json", "threshold_sweep.json",
           "ab_fuse_finish.json", "coarse_clock.json"):
     if os.path.exists(os.path.join(F, f)) and os.path.getsize(os.path.join(F, f)) > 0:
         shutil.copy(os.path.join(F, f), os.path.join(P, f))

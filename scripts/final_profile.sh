@@ -23,6 +23,7 @@ timeout -k 10 300 python scripts/engine_compare_lidar.py > "$O/engines_lidar_raw
 timeout -k 10 100 python scripts/event_overhead.py > "$O/event_overhead.txt" 2>&1 || exit 1
 # C5 at stream length: 200 synthetic frames as KITTI .bin, file -> pose, with the oracle loop beside it
 timeout -k 10 600 python scripts/run_sequence.py --make-synthetic /tmp/drive200 --frames 0:200 --oracle > "$O/sequence_200.json" 2> "$O/sequence_200.err" || exit 1
+timeout -k 10 300 python scripts/run_sequence.py --data_dir /tmp/drive200 --frames 0:200 --no-prefetch > "$O/sequence_200_noprefetch.json" 2> /dev/null || exit 1
 # ... and with the map side of every frame (world points + occupancy grid), the cell set compared with the oracle's
 timeout -k 10 600 python scripts/run_sequence.py --data_dir /tmp/drive200 --frames 0:200 --oracle --map > "$O/sequence_200_map.json" 2> "$O/sequence_200_map.err" || exit 1
 # same-box A/B of the fused finish + step + transform kernel, and the clock inside the coarse kernel
