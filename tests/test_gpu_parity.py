@@ -293,6 +293,14 @@ def test_voxel_downsample_lidar_frame_and_edge_cases(gpu_ctx, oracle):
     # a NaN point is UB in the reference (cast of floor(NaN)); here it must only be harmless
     out = gpu_ctx.voxel_downsample(np.array([[0.1, 0, 0], [np.nan, 0, 0], [0.2, 0, 0]]), 0.5)
     assert 1 <= out.shape[0] <= 3
+    # small and large grids: 13+13+13 bits of cell offsets, 14+14+13, 17+17+17, and one axis at its 21-bit limit
+    rng = np.random.default_rng(77)
+    for extent, voxel in (((4.0, 4.0, 4.0), 1e-3), ((8.0, 8.0, 4.0), 1e-3), ((100.0, 100.0, 100.0), 1e-3),
+                          ((2000.0, 1.0, 1.0), 1e-3), ((50.0, 50.0, 3.0), 0.5)):
+        pts = rng.uniform(0, 1, (6000, 3)) * np.array(extent)
+        pts[0:5600:7] = pts[1:5600:7]                                    # some shared voxels
+        got, want = gpu_ctx.voxel_downsample(pts, voxel), oracle.voxel_downsample(pts, voxel)
+        assert got.shape == want.shape and (got == want).all()
 
 
 def test_voxel_then_align_on_device(gpu_ctx, oracle):
