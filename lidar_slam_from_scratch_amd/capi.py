@@ -443,16 +443,18 @@ class Context:
     def occupancy_clear(self):
         self._check(self._lib.icpmi_occupancy_clear(self._h))
 
-    def stream_map_update(self, pose, grid=None, want_world=True, update_grid=True):
-        """slam_node.cpp:147-153 on the scan the last stream_push* left resident: (world points or None, cells in the set)"""
+    def stream_map_update(self, pose, grid=None, want_world=True, update_grid=True, n_rows=None):
+        """slam_node.cpp:147-153 on the scan the last stream_push* left resident: (world points or None, cells in the set).
+        n_rows: the filtered scan's row count (info.n_filtered of the push), which saves asking the library for it."""
         T = np.ascontiguousarray(pose, dtype=np.float64).reshape(16)
         nw, nc = C.c_int64(0), C.c_int64(0)
         g = (grid if grid is not None else self.make_grid_config()) if update_grid else None
         world = None
         if want_world:
-            # the row count is the filtered scan's, known to the caller from the push; ask first to stay general
-            self._check(self._lib.icpmi_stream_map_update(self._h, _dp(T), None, None, 0, C.byref(nw), C.byref(nc)))
-            world = np.empty((nw.value, 3))
+            if n_rows is None:
+                self._check(self._lib.icpmi_stream_map_update(self._h, _dp(T), None, None, 0, C.byref(nw), C.byref(nc)))
+                n_rows = nw.value
+            world = np.empty((int(n_rows), 3))
         self._check(self._lib.icpmi_stream_map_update(self._h, _dp(T), C.byref(g) if g is not None else None,
                                                       _dp(world) if world is not None else None,
                                                       world.shape[0] if world is not None else 0, C.byref(nw), C.byref(nc)))

@@ -148,9 +148,9 @@ def run_odometry_stream(paths, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6
     if grid is not None:
         ctx.occupancy_clear()
 
-    def map_side():
+    def map_side(n_rows):
         if grid is not None:                                      # slam_node.cpp:147-153
-            _w, n_cells = ctx.stream_map_update(track.poses[-1], grid, want_world=want_world)
+            _w, n_cells = ctx.stream_map_update(track.poses[-1], grid, want_world=want_world, n_rows=n_rows)
             track.cells.append(n_cells)
 
     paths = list(paths)
@@ -178,7 +178,7 @@ def run_odometry_stream(paths, ctx, voxel=0.5, max_iterations=50, tolerance=1e-6
         track.iterations.append(res.num_iterations)
         track.converged.append(bool(res.converged))
         track.gated.append(bool(bad))
-        map_side()
+        map_side(info.n_filtered)
         track.frame_ms.append(1e3 * (time.perf_counter() - t0))
     return track
 
