@@ -440,7 +440,7 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
 {
     const int splits = ctx->nn_splits;
     int rc;
-    if ((rc = reserve(ctx, ctx->coarse, sizeof(float2) * (size_t)splits * n))) return rc;
+    if ((rc = reserve(ctx, ctx->coarse, coarse_bytes(splits, n)))) return rc;
     const SplitFrame *frames = (const SplitFrame *)ctx->frames.p;
     const unsigned *perm = (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m;
     unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);

@@ -99,12 +99,21 @@ struct NnFrame {     // bounding box of the whole target (Morton quantisation)
 #define ICPMI_SY(sorted, ms, j) (sorted)[(size_t)(ms) + (j)]
 #define ICPMI_SZ(sorted, ms, j) (sorted)[2 * (size_t)(ms) + (j)]
 
-// The coarse minima of the 1-NN pass are two planes of one buffer: x[split][n] (smallest column
-// minimum, tagged with its column) and y[split][n] (second smallest).  The resolve reads all of x
-// (phase 1) and only a handful of y (certificate candidates): as float2 records every 4-byte read
-// of x dragged its y along.
+// The coarse minima of the 1-NN pass are two planes of one buffer: x[split][n], fp32 (smallest column
+// minimum, tagged with its column), and y[split][n], bf16 (second smallest, ROUNDED DOWN: the upper
+// half of the fp32 word of a non-negative value, negative ones stored as 0).  The resolve reads all
+// of x (phase 1) and a handful of y (certificate candidates), and y is only ever asked "<= bound?"
+// with a non-negative bound, which a value that never exceeds the true one answers with a superset:
+// 6 bytes per (query, split) instead of 8.
 #define ICPMI_CX(coarse, n, nsplits, s, i) (reinterpret_cast<const float *>(coarse))[(size_t)(s) * (n) + (i)]
-#define ICPMI_CY(coarse, n, nsplits, s, i) (reinterpret_cast<const float *>(coarse))[((size_t)(nsplits) + (s)) * (size_t)(n) + (i)]
+#define ICPMI_CY(coarse, n, nsplits, s, i)                                                                                   \
+    __uint_as_float((unsigned)(reinterpret_cast<const unsigned short *>(reinterpret_cast<const float *>(coarse) +            \
+                                                                        (size_t)(nsplits) * (size_t)(n)))[(size_t)(s) * (n) + (i)] \
+                    << 16)
+__host__ __device__ inline size_t coarse_bytes(int nsplits, int n)
+{
+    return (sizeof(float) + sizeof(unsigned short)) * (size_t)nsplits * (size_t)n + 16;
+}
 
 struct SplitFrame {  // per split of 2048 sorted targets
     double c[3];     // centre the split's operands are expressed about
@@ -563,7 +572,8 @@ __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const
             if (half == 0 && iq < n) {
                 float *plane = reinterpret_cast<float *>(coarse);
                 plane[(size_t)s * n + iq] = v1;
-                plane[((size_t)nsplits + s) * (size_t)n + iq] = v2;
+                unsigned short *yplane = reinterpret_cast<unsigned short *>(plane + (size_t)nsplits * (size_t)n);
+                yplane[(size_t)s * n + iq] = (unsigned short)(__float_as_uint(max_raw(v2, 0.f)) >> 16); // bf16, rounded down
             }
         }
     }
