@@ -13,6 +13,9 @@
 //   slam::estimate_normals      icp.hpp:23-67            estimate_normals
 //   slam::solve_point_to_plane  icp.hpp:89-144           solve_point_to_plane
 //   (north_star wording)                                 ICP::align
+//   slam::ScanContext           scan_context.hpp:44-142      ScanContext (compute, distance), scan_context_distances
+//   slam::LoopClosureConfig / LoopClosureResult / LoopClosureDetector
+//                               loop_closure.hpp:14-148      LoopClosureConfig, LoopClosureResult, LoopClosureDetector
 //   SlamNode::process_frame, registration and map side   OdometryStream (push, map_update)
 //     (slam_viz/src/ros/slam_node.cpp:118-157)
 //   OccupancyGridConfig / GridCell / update_occupancy_grid / cells_to_occupancy_grid_msg
@@ -23,6 +26,7 @@
 // slam_icp_adapter.hpp instead, which keeps slam::icp_point_to_plane's exact signature.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstddef>
@@ -506,6 +510,117 @@ private:
     }
     Context *ctx_;
     std::size_t last_filtered_ = 0;
+};
+
+// ---- loop closure: Scan Context candidates + ICP verification (core/scan_context.hpp, core/loop_closure.hpp) ----
+// slam::ScanContext: the 20 x 60 max-height descriptor and its column-shift cosine distance.
+class ScanContext {
+public:
+    static constexpr int kRings = ICPMI_SC_RINGS, kSectors = ICPMI_SC_SECTORS;
+    ScanContext() : d_(static_cast<std::size_t>(kRings) * kSectors, 0.0) {}
+    static ScanContext compute(const PointCloud &cloud, Context *ctx = nullptr) // scan_context.hpp:44-82
+    {
+        Context &c = ctx ? *ctx : default_context();
+        ScanContext sc;
+        const int rc = icpmi_scan_context(c.get(), cloud.data(), static_cast<int64_t>(cloud.size()), sc.d_.data());
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(c.get()));
+        return sc;
+    }
+    double distance(const ScanContext &other, Context *ctx = nullptr) const // scan_context.hpp:90-101
+    {
+        Context &c = ctx ? *ctx : default_context();
+        double d = 0.0;
+        const int rc = icpmi_scan_context_distances(c.get(), d_.data(), other.d_.data(), 1, &d);
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(c.get()));
+        return d;
+    }
+    const std::vector<double> &descriptor() const { return d_; } // row-major [ring][sector]
+
+private:
+    std::vector<double> d_;
+};
+
+struct LoopClosureConfig { // loop_closure.hpp:14-19
+    int frame_gap = 50;
+    double sc_distance_threshold = 0.25;
+    double icp_fitness_threshold = 0.3;
+    int max_candidates = 3;
+};
+struct LoopClosureResult { // loop_closure.hpp:25-31
+    int query_frame = 0, match_frame = 0;
+    Transformation transform;
+    double scan_context_distance = 0.0, icp_fitness = 0.0;
+};
+
+// slam::LoopClosureDetector (loop_closure.hpp:41-148): keeps every frame's cloud and descriptor, and
+// detect() looks for closures of the most recently added frame -- the distances of its descriptor to the
+// whole history in ONE device call, the candidate filter and the sort on the host as in the reference,
+// up to max_candidates ICP verifications (30 iterations, tolerance 1e-6, :102-109) through the C ABI.
+class LoopClosureDetector {
+public:
+    explicit LoopClosureDetector(LoopClosureConfig config = LoopClosureConfig(), Context *ctx = nullptr)
+        : config_(config), ctx_(ctx ? ctx : &default_context())
+    {
+    }
+    void addFrame(const PointCloud &cloud, int frame_idx) // loop_closure.hpp:53-60
+    {
+        const ScanContext sc = ScanContext::compute(cloud, ctx_);
+        descriptors_.insert(descriptors_.end(), sc.descriptor().begin(), sc.descriptor().end());
+        clouds_.push_back(cloud.copy());
+        frame_indices_.push_back(frame_idx);
+    }
+    std::size_t size() const { return frame_indices_.size(); }
+    void clear()
+    {
+        descriptors_.clear();
+        clouds_.clear();
+        frame_indices_.clear();
+    }
+    std::vector<LoopClosureResult> detect() // loop_closure.hpp:66-126
+    {
+        std::vector<LoopClosureResult> results;
+        if (frame_indices_.size() < 2) return results; // :69
+        constexpr std::size_t kDesc = static_cast<std::size_t>(ScanContext::kRings) * ScanContext::kSectors;
+        const std::size_t q = frame_indices_.size() - 1;
+        std::vector<double> dist(q);
+        const int rc = icpmi_scan_context_distances(ctx_->get(), descriptors_.data() + q * kDesc, descriptors_.data(),
+                                                    static_cast<int64_t>(q), dist.data()); // :84 for every i
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx_->get()));
+        std::vector<std::pair<double, int>> candidates;
+        for (std::size_t i = 0; i < q; ++i) {
+            if (frame_indices_[q] - frame_indices_[i] < config_.frame_gap) continue;                       // :80-82
+            if (dist[i] < config_.sc_distance_threshold) candidates.emplace_back(dist[i], static_cast<int>(i)); // :86-89
+        }
+        std::sort(candidates.begin(), candidates.end()); // :93
+        int verified = 0;
+        for (const auto &cand : candidates) {
+            if (verified >= config_.max_candidates) break; // :97
+            ICPConfig icp;                                 // :102-105
+            icp.max_iterations = 30;
+            icp.tolerance = 1e-6;
+            const ICPResult r = icp_point_to_plane(*ctx_, clouds_[q].data(), clouds_[q].size(), clouds_[cand.second].data(),
+                                                   clouds_[cand.second].size(), icp);            // :109
+            if (r.converged && r.final_error < config_.icp_fitness_threshold) {                  // :112
+                LoopClosureResult out;
+                out.query_frame = frame_indices_[q];
+                out.match_frame = frame_indices_[cand.second];
+                out.transform = r.transformation;
+                out.scan_context_distance = cand.first;
+                out.icp_fitness = r.final_error;
+                results.push_back(out);
+                ++verified;
+            }
+        }
+        return results;
+    }
+    const LoopClosureConfig &config() const { return config_; }
+
+private:
+    LoopClosureConfig config_;
+    Context *ctx_;
+    std::vector<double> descriptors_; // 1200 per frame, frame-major
+    std::vector<PointCloud> clouds_;
+    std::vector<int> frame_indices_;
 };
 
 // `ICP(config).align(source, target)`: the facade BASELINE.json's north_star names.

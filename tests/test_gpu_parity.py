@@ -384,6 +384,46 @@ def test_loop_closure_detector_matches_oracle(gpu_ctx, oracle):
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and abs(a.icp_fitness - b.icp_fitness) < 1e-9
 
 
+def test_cpp_loop_closure_mirror(tmp_path):
+    """include/icp_mi355x.hpp's ScanContext / LoopClosureDetector from a plain C++17 program
+    (tests/cpp/loop_demo.cpp) against the Python mirror through the same C ABI: same closures, same
+    Scan Context distances and ICP fitness, same transforms."""
+    import subprocess
+    from lidar_slam_from_scratch_amd import build, loop_closure as lc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "loop_demo"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "loop_demo.cpp"), "-o", str(exe), build.LIB_PATH,
+                           "-Wl,-rpath," + os.path.dirname(build.LIB_PATH), "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
+                           "-lamdhip64"])
+    order = [0, 2, 4, 6, 8, 10, 12, 1, 3]      # frames 1 and 3 revisit the start of the drive
+    clouds = [_off_sector_boundaries(synth.lidar_frame(f, beams=32, azimuths=900)) for f in order]
+    files = []
+    for k, c in enumerate(clouds):
+        c.tofile(tmp_path / ("c%d.f64" % k))
+        files.append(str(tmp_path / ("c%d.f64" % k)))
+    subprocess.check_call([str(exe), str(tmp_path / "o.f64"), "5", "0.2", "0.3"] + files)
+    o = np.fromfile(tmp_path / "o.f64")
+    gpu_ctx = capi.Context(device=0)            # the program's default context: search AUTO (exact comparisons below)
+    det = lc.LoopClosureDetector(lc.GpuBackend(gpu_ctx), lc.LoopClosureConfig(frame_gap=5, sc_distance_threshold=0.2,
+                                                                              icp_fitness_threshold=0.3))
+    want = []
+    for k, c in enumerate(clouds):
+        det.add_frame(c, k)
+        want.extend(det.detect())
+    n = int(o[0])
+    assert n == len(want) and n >= 1
+    p = 1
+    for w in want:
+        assert (int(o[p]), int(o[p + 1])) == (w.query_frame, w.match_frame)
+        assert o[p + 2] == w.scan_context_distance and o[p + 3] == w.icp_fitness
+        assert (o[p + 4:p + 20].reshape(4, 4) == np.asarray(w.transform).reshape(4, 4)).all()
+        p += 20
+    assert o[p] == gpu_ctx.scan_context_distances(gpu_ctx.scan_context(clouds[-1]), gpu_ctx.scan_context(clouds[0])[None])[0]
+    assert int(o[p + 1]) == len(clouds)
+    gpu_ctx.close()
+
+
 # ------------------------------------------------------------------ odometry stream (SURVEY 8f N3)
 def test_odometry_stream_matches_oracle(gpu_ctx, oracle):
     """process_frame minus ROS (slam_node.cpp:118-157) over a short synthetic drive: same
