@@ -140,10 +140,17 @@ struct icpmi_ctx {
     DevBuf vox_keys, vox_vals, vox_out;             // voxel filter: 64-bit keys (in/out/unique), values + run data, result
     DevBuf stream_prev, stream_cur, f32_stage;      // odometry stream: previous / current filtered scan; float32 upload staging
     int64_t stream_prev_n = -1;                     // rows of stream_prev (-1: no frame yet)
+    int64_t stream_cur_n = 0;                       // rows of stream_cur while a push is registering it
     DevBuf grid_set, grid_in, grid_out, grid_cnt, world; // occupancy grid: the set (sorted unique keys), {set, new keys}, sorted, run data; world points
     int64_t grid_n = 0;                             // cells in grid_set
     unsigned *h_grid = nullptr;                     // pinned: the set's size on its way back
     FilePrefetch *prefetch = nullptr;               // worker reading the next frame file (icpmi_stream_prefetch_file)
+    // the target whose search structure and normals the context's buffers currently hold (prepare_target):
+    // icpmi_stream_push prepares the NEXT frame's target while the caller is still busy with this frame's result
+    const double *prep_tgt = nullptr;
+    int prep_m = 0, prep_engine = 0;
+    bool prep_valid = false;
+    hipEvent_t result_ready = nullptr;              // recorded behind a call's result copies (stream path)
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     DevBuf src_sort, blk_lists, work;         // pruned engine: Morton order of the source, per-block split lists, unit list
@@ -341,8 +348,17 @@ int finish_transform_blocks(int n)
 // Choose and prepare the search engine for a target cloud (once per call: the target does
 // not move).  Both engines return the same indices; AUTO takes the MFMA engine once the
 // pair count makes its fixed costs (Morton sort, operand packing, resolve) worthwhile.
+int engine_for(const icpmi_ctx *ctx, int m, int n_hint)
+{
+    int engine = ctx->opt.search;
+    if (engine == ICPMI_SEARCH_AUTO)
+        engine = (m >= mfma_min_targets() && n_hint >= kMfmaMinQueries) ? ICPMI_SEARCH_MFMA_BF16 : ICPMI_SEARCH_EXACT_F64;
+    return engine;
+}
+
 int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
 {
+    ctx->prep_valid = false; // whatever target the buffers held: it is being replaced
     int engine = ctx->opt.search;
     if (engine == ICPMI_SEARCH_AUTO)
         engine = (m >= mfma_min_targets() && n_hint >= kMfmaMinQueries) ? ICPMI_SEARCH_MFMA_BF16 : ICPMI_SEARCH_EXACT_F64;
@@ -696,9 +712,30 @@ int exchange_allgather(icpmi_ctx *ctx, double *d_buf, size_t per)
 }
 
 // ---- the ICP call, device pointers -----------------------------------------------------
+// Search structure + normals of a target for a single-GPU registration (icp.hpp:169-171), queued on the
+// context's stream; remembered, so that an align against the same device pointer and size with the
+// same engine finds them in place.  Everything else that prepares a search (prepare_nn) forgets it.
+int prepare_target(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
+{
+    int rc;
+    if ((rc = reserve(ctx, ctx->nrm, sizeof(double) * 3 * (size_t)m))) return rc;
+    if ((rc = prepare_nn(ctx, d_tgt, m, n_hint))) return rc;
+    const bool sorted_rows = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && ctx->nn_pruned && ctx->opt.normal_k <= 32 &&
+                             m >= mfma_min_targets();
+    if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, 0, m, (double *)ctx->nrm.p, sorted_rows, true))) return rc;
+    ctx->prep_tgt = d_tgt;
+    ctx->prep_m = m;
+    ctx->prep_engine = engine_for(ctx, m, n_hint);
+    ctx->prep_valid = true;
+    return ICPMI_OK;
+}
+
+// `before_wait` (may be null): called once everything of the registration, the copies of its results
+// included, is queued and an event behind them recorded -- what it queues runs while the host waits
+// for that event only (icpmi_stream_push prepares the next frame's target there).
 int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const double *d_tgt,
                  int64_t n_tgt64, const icpmi_config *cfg, icpmi_result *result,
-                 double *error_history, int32_t history_cap)
+                 double *error_history, int32_t history_cap, int (*before_wait)(icpmi_ctx *) = nullptr)
 {
     const int n = (int)n_src64, m = (int)n_tgt64;
     const int max_it = cfg->max_iterations;
@@ -733,7 +770,10 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     IcpState *st = ctx->d_state;
     HIP_TRY(ctx, hipMemcpyAsync(st, hs, sizeof(IcpState), hipMemcpyHostToDevice, s));
 
-    if ((rc = prepare_nn(ctx, d_tgt, m, n))) return rc;
+    const bool sharded_run = ctx->comm != nullptr || ctx->cb_allreduce != nullptr;
+    const bool prepared = !sharded_run && ctx->prep_valid && ctx->prep_tgt == d_tgt && ctx->prep_m == m &&
+                          ctx->prep_engine == engine_for(ctx, m, n);
+    if (!prepared && (rc = prepare_nn(ctx, d_tgt, m, n))) return rc;
     // with the MFMA engine the resolve kernel also forms the normal-equation partial sums
     const bool fused = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16;
     const int rblocks = fused ? resolve_blocks(n) : reduce_blocks(ctx, n);
@@ -761,9 +801,10 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         else
             HIP_TRY(ctx, hipMemcpyAsync(nrm, gathered, sizeof(double) * 3 * (size_t)m,
                                         hipMemcpyDeviceToDevice, s));
-    } else {
+    } else if (!prepared) {
         if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, 0, m, nrm, sorted_rows, true))) return rc;
     }
+    ctx->prep_valid = false; // (the stream path prepares the next target below; nothing else relies on it)
 
     // Pruned engine: the source is put in Morton order once (a rigid motion keeps neighbours
     // together), so that every block of kCoarseQueries consecutive rows of `cur` is a compact
@@ -916,7 +957,16 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     }
     HIP_TRY(ctx, hipMemcpyAsync(hs, st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     if (hcopy > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist, hist, sizeof(double) * (size_t)hcopy, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (before_wait && ctx->opt.profile == 0) {
+        // the results are waited for through an event; what before_wait queues behind it keeps the device busy
+        // while the caller digests them (with profiling on, the stage timers want the whole stream drained)
+        if (!ctx->result_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->result_ready, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ctx->result_ready, s));
+        (void)before_wait(ctx); // (a failure there only means the next call prepares its target itself)
+        HIP_TRY(ctx, hipEventSynchronize(ctx->result_ready));
+    } else {
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
     HIP_TRY(ctx, hipGetLastError());
     const int hl = std::min(hs->hist_len, max_hist);
     if (hl > 0) memcpy(error_history, ctx->h_hist, sizeof(double) * (size_t)std::min(hl, history_cap));
@@ -1156,6 +1206,7 @@ void icpmi_destroy(icpmi_ctx *ctx)
                       &ctx->grid_in, &ctx->grid_out, &ctx->grid_cnt, &ctx->world})
         release(*b);
     if (ctx->h_grid) (void)hipHostFree(ctx->h_grid);
+    if (ctx->result_ready) (void)hipEventDestroy(ctx->result_ready);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_hist) (void)hipHostFree(ctx->h_hist);
@@ -1657,6 +1708,7 @@ int icpmi_stream_reset(icpmi_ctx *ctx)
 {
     if (!ctx) return ICPMI_ERR_NULL;
     ctx->stream_prev_n = -1;
+    ctx->prep_valid = false;
     return ICPMI_OK;
 }
 
@@ -1680,18 +1732,30 @@ int icpmi_stream_push(icpmi_ctx *ctx, const double *d_raw_xyz, int64_t n_raw, do
     if ((rc = voxel_downsample_device(ctx, d_raw_xyz, (int)n_raw, voxel_size, (double *)ctx->stream_cur.p, n_raw, &n_cur, false))) return rc;
     info->n_filtered = n_cur;
     info->n_target = ctx->stream_prev_n < 0 ? 0 : ctx->stream_prev_n;
+    ctx->stream_cur_n = n_cur;
+    // The scan just filtered is the NEXT push's target (slam_node.cpp:128,152): its search structure and
+    // normals are queued now -- behind this push's registration, before the host waits for its result --
+    // so that the device builds them while the caller digests this frame (pose update, map, next file);
+    // the next push finds them in place (align_device: `prepared`).
+    auto prepare_next = [](icpmi_ctx *c) -> int {
+        if (c->stream_cur_n <= 0 || (c->comm != nullptr || c->cb_allreduce != nullptr)) return ICPMI_OK;
+        return prepare_target(c, (const double *)c->stream_cur.p, (int)c->stream_cur_n, (int)c->stream_cur_n);
+    };
+    bool queued_next = false;
     if (ctx->stream_prev_n < 0) {
         info->status = ICPMI_STREAM_FIRST_FRAME;          // slam_node.cpp:69-72: nothing to register against yet
     } else if (n_cur < min_points || n_cur <= 0 || ctx->stream_prev_n <= 0) { // (an empty cloud on either side is UB in the reference)
         info->status = ICPMI_STREAM_TOO_FEW_POINTS;       // slam_node.cpp:125-130: the caller repeats its last pose
     } else {
         // source = curr, target = prev (slam_node.cpp:132-133): both already in HBM; the target's
-        // search structure and normals are built from the resident copy
+        // search structure and normals are built from the resident copy (by the previous push, as a rule)
         info->status = ICPMI_STREAM_REGISTERED;
+        queued_next = ctx->opt.profile == 0;
         if ((rc = align_device(ctx, (const double *)ctx->stream_cur.p, n_cur, (const double *)ctx->stream_prev.p,
-                               ctx->stream_prev_n, cfg, result, error_history, history_cap)))
+                               ctx->stream_prev_n, cfg, result, error_history, history_cap, +prepare_next)))
             return rc;
     }
+    if (!queued_next && ctx->opt.profile == 0) (void)prepare_next(ctx); // (a failure only means the next push prepares it itself)
     std::swap(ctx->stream_prev, ctx->stream_cur);         // prev_points_ = curr (slam_node.cpp:128,152), no copy
     ctx->stream_prev_n = n_cur;
     return ICPMI_OK;

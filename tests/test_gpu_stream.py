@@ -212,3 +212,45 @@ def test_prefetched_frames_give_the_same_stream(tmp_path):
     assert r3.num_iterations == a.iterations[2]
     ctx.stream_prefetch_file(paths[4])                       # left pending: close() must stop the worker
     ctx.close()
+
+
+def test_early_target_preparation_survives_foreign_calls(tmp_path, oracle):
+    """A push queues the search structure and normals of the scan it has just filtered (the next push's target)
+    behind its own result.  Calls in between that use the same buffers for other clouds -- a search, normals, a
+    registration, a voxel filter, a map update -- must make the next push prepare its target again; the stream's
+    results stay those of the undisturbed stream, and a context with stage timers (no early preparation) agrees."""
+    import run_sequence
+    run_sequence.write_synthetic_drive(str(tmp_path), 0, 8, beams=32, azimuths=900)
+    paths = [p for _, p in capi.discover_frames(str(tmp_path))]
+    ctx = capi.Context(device=0)
+    plain = odometry.run_odometry_stream(paths, ctx, prefetch=False)
+    timed = capi.Context(device=0, profile=2)
+    with_timers = odometry.run_odometry_stream(paths, timed, prefetch=False)
+    assert with_timers.iterations == plain.iterations and all((a == b).all() for a, b in zip(with_timers.poses, plain.poses))
+    timed.close()
+    rng = np.random.default_rng(2)
+    other_a, other_b = rng.uniform(-20, 20, (3000, 3)), rng.uniform(-20, 20, (2500, 3))
+    cfg = capi.Context.make_config()
+    ctx.stream_reset()
+    its, Ts = [], []
+    for k, p in enumerate(paths):
+        res, _, info = ctx.stream_push_file(p, 0.5, 1000, cfg)
+        if info.status == capi.STREAM_REGISTERED:
+            its.append(res.num_iterations)
+            Ts.append(np.array(res.transformation[:]))
+        # something else happens on the context between two frames
+        if k % 4 == 0:
+            idx, _ = ctx.nearest_batch(other_a, other_b)
+            assert (idx == oracle.KDTree(other_a).nearest_batch(other_b)[0]).all()
+        elif k % 4 == 1:
+            ctx.estimate_normals(other_a, 20)
+        elif k % 4 == 2:
+            ctx.align(other_b, other_a, capi.Context.make_config(max_iterations=3))
+        else:
+            ctx.voxel_downsample(other_a, 0.5)
+            ctx.stream_map_update(np.eye(4))
+    assert its == plain.iterations
+    for T, d in zip(Ts, plain.deltas):
+        if not (d == np.eye(4)).all():          # (gated frames carry the identity in the track)
+            assert (T.reshape(4, 4) == d).all()
+    ctx.close()
