@@ -234,13 +234,14 @@ int icpmi_stream_push_host(icpmi_ctx *ctx, const double *raw_xyz, int64_t n_raw,
 int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, int64_t min_points,
                            const icpmi_config *cfg, icpmi_result *result, double *error_history,
                            int32_t history_cap, icpmi_stream_info *info);
-/* Start reading the NEXT frame file into pinned memory on a worker thread of the context and return at
- * once; the icpmi_stream_push_file of that same path then finds the bytes there (it waits for the
- * read if it is still going on).  Call it BEFORE pushing the current frame: the read (~140 us for a
- * 1.8 MB scan out of the page cache, and nothing of the GPU's) then runs beside the current frame's
- * work.  KITTI ".bin" only (a PLY is parsed when pushed: the call is a no-op); one read at a time, one
- * finished file kept until the push of its path takes it (a later finished read replaces it); a file
- * that cannot be read is reported by the push.  Never needed for correctness. */
+/* Start bringing the NEXT frame file to the device on a worker thread of the context and return at once:
+ * the file is read into pinned memory (~140 us for a 1.8 MB scan out of the page cache), copied over on a
+ * stream of the worker's own and widened there; the icpmi_stream_push_file of that same path then finds the
+ * points in device memory (it waits for the worker if it is still busy with that file).  Call it BEFORE
+ * pushing the current frame: read and copy then run beside the current frame's work.  KITTI ".bin" only (a
+ * PLY is parsed when pushed: the call is a no-op); one file at a time; a finished file is kept until the
+ * push of its path takes it (at most two wait, the older gives way to a third); a file that cannot be read
+ * is reported by the push.  Never needed for correctness. */
 int icpmi_stream_prefetch_file(icpmi_ctx *ctx, const char *path);
 int icpmi_stream_reset(icpmi_ctx *ctx);   /* forget the resident frame (a new sequence starts) */
 

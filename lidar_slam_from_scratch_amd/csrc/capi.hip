@@ -114,17 +114,28 @@ struct Rccl {
 
 } // namespace
 
-// A KITTI .bin on its way from disk into pinned memory, read by a worker thread while the caller's
-// thread runs the previous frame (icpmi_stream_prefetch_file): the read of a 1.8 MB scan out of the
-// page cache takes ~140 us, a fifth of a frame, and needs nothing of the GPU.
+// A KITTI .bin on its way from disk to the device while the caller's thread runs the previous frame
+// (icpmi_stream_prefetch_file): a worker thread reads it into pinned memory (~140 us for a 1.8 MB scan
+// out of the page cache, nothing of the GPU's), copies it over on a stream of its own (the copy engine
+// runs beside the compute of the frame in flight; on the context's stream it would queue behind it) and
+// widens it there (k_widen_f32).  Two device slots: the push of a frame works out of one while the next
+// frame lands in the other.
 struct FilePrefetch {
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv;
     std::string want;         // path being read (valid while `busy`)
-    std::string ready;        // path whose bytes wait in `ready_buf` for the push of that path
-    void *work_buf = nullptr, *ready_buf = nullptr; // pinned; the worker fills work_buf and swaps it in when done
-    size_t work_cap = 0, ready_cap = 0, ready_bytes = 0;
+    std::string ready[2];     // per device slot: the path whose points wait there for the push of that path
+    void *h_buf = nullptr;    // pinned staging (the worker's alone)
+    size_t h_cap = 0;
+    void *d_f32[2] = {nullptr, nullptr};   // device: the float32 records as read
+    double *d_raw[2] = {nullptr, nullptr}; // device: N x 3 fp64 raw points
+    size_t d_cap[2] = {0, 0};              // records each slot holds
+    int64_t ready_n[2] = {0, 0};
+    unsigned long long ready_seq[2] = {0, 0}, seq = 0; // which pending file is the older one
+    hipEvent_t slot_done[2] = {nullptr, nullptr};      // recorded on the context's stream behind the push that read a slot
+    bool slot_used[2] = {false, false};                // ... if any push has read it yet
+    hipStream_t stream = nullptr;
     bool busy = false, quit = false;
     int device = 0;
 };
@@ -1192,8 +1203,14 @@ void icpmi_destroy(icpmi_ctx *ctx)
         }
         pf->cv.notify_all();
         if (pf->worker.joinable()) pf->worker.join();
-        if (pf->work_buf) (void)hipHostFree(pf->work_buf);
-        if (pf->ready_buf) (void)hipHostFree(pf->ready_buf);
+        if (pf->h_buf) (void)hipHostFree(pf->h_buf);
+        for (int k = 0; k < 2; ++k) {
+            if (pf->d_f32[k]) (void)hipFree(pf->d_f32[k]);
+            if (pf->d_raw[k]) (void)hipFree(pf->d_raw[k]);
+        }
+        if (pf->stream) (void)hipStreamDestroy(pf->stream);
+        for (int k = 0; k < 2; ++k)
+            if (pf->slot_done[k]) (void)hipEventDestroy(pf->slot_done[k]);
         delete pf;
         ctx->prefetch = nullptr;
     }
@@ -1775,38 +1792,58 @@ void prefetch_worker(FilePrefetch *pf)
         pf->cv.wait(lk, [pf] { return pf->quit || pf->busy; });
         if (pf->quit) return;
         const std::string path = pf->want;
+        // the slot to fill: an empty one, else the older of two files that were prefetched but never pushed.  A push
+        // may have read the slot: its kernels are behind the event it recorded (another stream than this thread's)
+        const int slot = pf->ready[0].empty() ? 0 : (pf->ready[1].empty() ? 1 : (pf->ready_seq[0] < pf->ready_seq[1] ? 0 : 1));
+        pf->ready[slot].clear();
+        const bool wait_for_push = pf->slot_used[slot];
         lk.unlock();
-        // (work_buf is this thread's while `busy` is set; ready_buf changes hands under the lock only)
+        if (wait_for_push) (void)hipEventSynchronize(pf->slot_done[slot]);
         bool ok = false;
-        size_t bytes = 0;
+        int64_t n = 0;
         if (FILE *f = fopen(path.c_str(), "rb")) {
             fseek(f, 0, SEEK_END);
             const long size = ftell(f);
             fseek(f, 0, SEEK_SET);
-            const int64_t n = size / (4 * (long)sizeof(float)); // file_utils.cpp:127
+            n = size / (4 * (long)sizeof(float)); // file_utils.cpp:127
             if (n > 0 && n <= 700000000) {
-                bytes = 4 * sizeof(float) * (size_t)n;
-                if (pf->work_cap < bytes) {
-                    if (pf->work_buf) (void)hipHostFree(pf->work_buf);
-                    pf->work_buf = nullptr;
-                    pf->work_cap = 0;
-                    if (hipHostMalloc(&pf->work_buf, bytes + bytes / 4, hipHostMallocDefault) == hipSuccess)
-                        pf->work_cap = bytes + bytes / 4;
+                const size_t bytes = 4 * sizeof(float) * (size_t)n;
+                if (pf->h_cap < bytes) {
+                    if (pf->h_buf) (void)hipHostFree(pf->h_buf);
+                    pf->h_buf = nullptr;
+                    pf->h_cap = 0;
+                    if (hipHostMalloc(&pf->h_buf, bytes + bytes / 4, hipHostMallocDefault) == hipSuccess) pf->h_cap = bytes + bytes / 4;
                 }
-                if (pf->work_cap >= bytes) {
-                    const size_t got = fread(pf->work_buf, 1, bytes, f);
-                    if (got < bytes) memset((char *)pf->work_buf + got, 0, bytes - got); // like the synchronous path
-                    ok = true;
+                if (pf->d_cap[slot] < (size_t)n) {
+                    if (pf->d_f32[slot]) (void)hipFree(pf->d_f32[slot]);
+                    if (pf->d_raw[slot]) (void)hipFree(pf->d_raw[slot]);
+                    pf->d_f32[slot] = nullptr;
+                    pf->d_raw[slot] = nullptr;
+                    pf->d_cap[slot] = 0;
+                    const size_t cap = (size_t)n + (size_t)n / 4;
+                    if (hipMalloc(&pf->d_f32[slot], 4 * sizeof(float) * cap) == hipSuccess &&
+                        hipMalloc((void **)&pf->d_raw[slot], 3 * sizeof(double) * cap) == hipSuccess)
+                        pf->d_cap[slot] = cap;
+                }
+                if (pf->h_cap >= bytes && pf->d_cap[slot] >= (size_t)n) {
+                    const size_t got = fread(pf->h_buf, 1, bytes, f);
+                    if (got < bytes) memset((char *)pf->h_buf + got, 0, bytes - got); // like the synchronous path
+                    if (!pf->stream) (void)hipStreamCreateWithFlags(&pf->stream, hipStreamNonBlocking);
+                    if (pf->stream && hipMemcpyAsync(pf->d_f32[slot], pf->h_buf, bytes, hipMemcpyHostToDevice, pf->stream) == hipSuccess) {
+                        hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pf->stream,
+                                           (const float *)pf->d_f32[slot], (int)n, 4, pf->d_raw[slot]);
+                        // the points are on the device before the file is announced: the push needs no event
+                        ok = hipStreamSynchronize(pf->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+                    }
                 }
             }
             fclose(f);
         }
         lk.lock();
-        if (ok) { // (a file that was ready but never pushed is dropped)
-            std::swap(pf->work_buf, pf->ready_buf);
-            std::swap(pf->work_cap, pf->ready_cap);
-            pf->ready = path;
-            pf->ready_bytes = bytes;
+        if (ok) {
+            pf->ready[slot] = path;
+            pf->ready_n[slot] = n;
+            pf->ready_seq[slot] = ++pf->seq;
         }
         pf->want.clear();
         pf->busy = false;
@@ -1829,7 +1866,7 @@ int icpmi_stream_prefetch_file(icpmi_ctx *ctx, const char *path)
     FilePrefetch *pf = ctx->prefetch;
     {
         std::unique_lock<std::mutex> lk(pf->mu);
-        if (pf->ready == path || (pf->busy && pf->want == path)) return ICPMI_OK; // already there / on its way
+        if (pf->ready[0] == path || pf->ready[1] == path || (pf->busy && pf->want == path)) return ICPMI_OK; // already there / on its way
         pf->cv.wait(lk, [pf] { return !pf->busy; }); // one read at a time
         pf->want = path;
         pf->busy = true;
@@ -1855,27 +1892,24 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
     }
     // KITTI .bin: the file is read into pinned memory and everything behind it -- copy, widening,
     // voxel filter, registration -- is queued on the context's stream without a wait in between
-    if (FilePrefetch *pf = ctx->prefetch) { // already read (or being read) by the worker?
+    if (FilePrefetch *pf = ctx->prefetch) { // already on the device (or on its way) thanks to the worker?
         std::unique_lock<std::mutex> lk(pf->mu);
         if (pf->busy && pf->want == path) pf->cv.wait(lk, [pf] { return !pf->busy; });
-        if (pf->ready == path) {
-            // take the worker's buffer, hand it ours (the copy out of ours finished with the previous push's wait)
-            std::swap(ctx->h_file, pf->ready_buf);
-            std::swap(ctx->h_file_cap, pf->ready_cap);
-            const size_t bytes = pf->ready_bytes;
-            pf->ready.clear();
+        const int slot = pf->ready[0] == path ? 0 : (pf->ready[1] == path ? 1 : -1);
+        if (slot >= 0) {
+            const int64_t n = pf->ready_n[slot];
+            // the slot stays marked as holding this path while the push reads it: the worker takes the other one
             lk.unlock();
-            const int64_t n = (int64_t)(bytes / (4 * sizeof(float)));
-            int rc2;
-            if ((rc2 = reserve(ctx, ctx->f32_stage, bytes))) return rc2;
-            if ((rc2 = reserve(ctx, ctx->stage_a, sizeof(double) * 3 * (size_t)n))) return rc2;
-            hipStream_t s = ctx->stream;
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->f32_stage.p, ctx->h_file, bytes, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)ctx->f32_stage.p, (int)n, 4,
-                               (double *)ctx->stage_a.p);
-            HIP_TRY(ctx, hipGetLastError());
-            return icpmi_stream_push(ctx, (const double *)ctx->stage_a.p, n, voxel_size, min_points, cfg, result, error_history,
-                                     history_cap, info);
+            const int rc2 = icpmi_stream_push(ctx, pf->d_raw[slot], n, voxel_size, min_points, cfg, result, error_history,
+                                              history_cap, info);
+            if (!pf->slot_done[slot]) (void)hipEventCreateWithFlags(&pf->slot_done[slot], hipEventDisableTiming);
+            const bool recorded = pf->slot_done[slot] && hipEventRecord(pf->slot_done[slot], ctx->stream) == hipSuccess;
+            if (!recorded) (void)hipStreamSynchronize(ctx->stream); // (then the slot is simply free)
+            lk.lock();
+            pf->slot_used[slot] = recorded;
+            pf->ready[slot].clear(); // free for the worker, behind the event
+            lk.unlock();
+            return rc2;
         }
         // not there (never asked for, or the worker could not read it): the synchronous path reads it and reports
     }
