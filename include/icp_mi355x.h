@@ -236,8 +236,9 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
                            int32_t history_cap, icpmi_stream_info *info);
 /* Start bringing the NEXT frame file to the device on a worker thread of the context and return at once:
  * the file is read into pinned memory (~140 us for a 1.8 MB scan out of the page cache), copied over on a
- * stream of the worker's own and widened there; the icpmi_stream_push_file of that same path then finds the
- * points in device memory (it waits for the worker if it is still busy with that file).  Call it BEFORE
+ * stream of the worker's own, widened and -- with the voxel size of the stream's last push -- filtered there;
+ * the icpmi_stream_push_file of that same path then starts at the registration (it waits for the worker if it
+ * is still busy with that file; with another voxel size it filters the raw points, already on the device, itself).  Call it BEFORE
  * pushing the current frame: read and copy then run beside the current frame's work.  KITTI ".bin" only (a
  * PLY is parsed when pushed: the call is a no-op); one file at a time; a finished file is kept until the
  * push of its path takes it (at most two wait, the older gives way to a third); a file that cannot be read

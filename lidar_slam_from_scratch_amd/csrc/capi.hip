@@ -138,6 +138,13 @@ struct FilePrefetch {
     hipStream_t stream = nullptr;
     bool busy = false, quit = false;
     int device = 0;
+    // ... and filtered there too (voxel_filter_core on the worker's stream, with working memory of its own), with the
+    // voxel size of the stream's last push: the push of the file then starts at the registration
+    double voxel_hint = 0.0;               // 0: no push yet, the worker stops after the widening
+    DevBuf filtered[2];                    // per slot: the filtered scan ...
+    int64_t filtered_n[2] = {0, 0};        // ... its rows ...
+    double filtered_voxel[2] = {0.0, 0.0}; // ... and the voxel size it was made with (0: not filtered)
+    DevBuf sc_bbox, sc_box, sc_keys, sc_vals, sc_tmp;
 };
 
 struct icpmi_ctx {
@@ -219,16 +226,23 @@ int fail(icpmi_ctx *ctx, int code, const char *fmt, ...)
                         hipGetErrorString(e_), __FILE__, __LINE__);                           \
     } while (0)
 
-int reserve(icpmi_ctx *ctx, DevBuf &b, size_t bytes)
+// grow-only with slack: odometry clouds vary frame to frame.  No context: also what the prefetch worker calls.
+hipError_t reserve_raw(DevBuf &b, size_t bytes)
 {
-    if (bytes <= b.cap) return ICPMI_OK;
-    if (b.p) HIP_TRY(ctx, hipFree(b.p));
+    if (bytes <= b.cap) return hipSuccess;
+    hipError_t e;
+    if (b.p && (e = hipFree(b.p)) != hipSuccess) return e;
     b.p = nullptr;
     b.cap = 0;
     size_t want = std::max(bytes, (size_t)4096);
-    want = want + want / 4; // grow-only with slack: odometry clouds vary frame to frame
-    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    want = want + want / 4;
+    if ((e = hipMalloc(&b.p, want)) != hipSuccess) return e;
     b.cap = want;
+    return hipSuccess;
+}
+int reserve(icpmi_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    HIP_TRY(ctx, reserve_raw(b, bytes));
     return ICPMI_OK;
 }
 
@@ -998,11 +1012,75 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
 // voxel filter on device memory -> d_out (n_out rows); see voxel.h
 // `finish`: wait for the centroids before returning (the public entry points promise complete
 // outputs; icpmi_stream_push queues the registration behind it on the same stream instead)
+// The voxel filter's working memory: the context has one set (shared with its other stages), the prefetch
+// worker another, so that it can filter the next scan on its own stream while the context registers this one.
+struct VoxelScratch {
+    DevBuf *bbox_part, *box, *keys, *vals, *tmp;
+    size_t box_offset; // of the VoxelBox inside *box
+};
+
+// No context in here (the worker thread runs it too): a code and a static message come back.
+int voxel_filter_core(hipStream_t s, VoxelScratch vs, const double *d_pts, int n, double voxel, double *d_out, int64_t out_cap,
+                      int64_t *n_out, bool finish, const char **msg)
+{
+#define VOX_TRY(call)                                   \
+    do {                                                \
+        const hipError_t e_ = (call);                   \
+        if (e_ != hipSuccess) {                         \
+            *msg = hipGetErrorString(e_);               \
+            return ICPMI_ERR_HIP;                       \
+        }                                               \
+    } while (0)
+    // key origin from the bounding box, formed on the device (k_voxel_keys)
+    const int bblocks = std::max(1, std::min(256, (n + 255) / 256));
+    VOX_TRY(reserve_raw(*vs.bbox_part, sizeof(double) * 6 * (size_t)bblocks));
+    VOX_TRY(reserve_raw(*vs.box, vs.box_offset + 64));
+    VoxelBox *box = (VoxelBox *)((char *)vs.box->p + vs.box_offset);
+    static_assert(sizeof(VoxelBox) == sizeof(NnFrame) && sizeof(VoxelBox) <= 64, "k_bbox_final writes an NnFrame here");
+    hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_pts, n, (double *)vs.bbox_part->p, 0);
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)vs.bbox_part->p, bblocks, (NnFrame *)box);
+    // keys_in | keys_out | unique ; vals_in | order | counts | offsets | runs, flag
+    const size_t un = (size_t)n;
+    VOX_TRY(reserve_raw(*vs.keys, sizeof(unsigned long long) * 3 * un));
+    VOX_TRY(reserve_raw(*vs.vals, sizeof(unsigned) * (4 * un + 16)));
+    unsigned long long *keys_in = (unsigned long long *)vs.keys->p, *keys_out = keys_in + un, *uniq = keys_in + 2 * un;
+    unsigned *vals_in = (unsigned *)vs.vals->p, *order = vals_in + un, *counts = vals_in + 2 * un,
+             *offsets = vals_in + 3 * un, *runs_d = vals_in + 4 * un;
+    size_t b1 = 0, b2 = 0, b3 = 0;
+    VOX_TRY(sort_pairs_u64(nullptr, &b1, keys_in, keys_out, vals_in, order, (unsigned)n, s));
+    VOX_TRY(run_lengths_u64(nullptr, &b2, keys_out, (unsigned)n, uniq, counts, runs_d, s));
+    VOX_TRY(exclusive_sum_u32(nullptr, &b3, counts, offsets, (unsigned)n, s));
+    VOX_TRY(reserve_raw(*vs.tmp, std::max(b1, std::max(b2, b3))));
+    hipLaunchKernelGGL(k_voxel_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_pts, n, voxel, (const VoxelBox *)box, runs_d + 1,
+                       keys_in, vals_in);
+    VOX_TRY(sort_pairs_u64(vs.tmp->p, &b1, keys_in, keys_out, vals_in, order, (unsigned)n, s));
+    VOX_TRY(run_lengths_u64(vs.tmp->p, &b2, keys_out, (unsigned)n, uniq, counts, runs_d, s));
+    unsigned runs_flag[2] = {0, 0};
+    VOX_TRY(hipMemcpyAsync(runs_flag, runs_d, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s)); // the call's one round trip
+    VOX_TRY(hipStreamSynchronize(s));
+    if (runs_flag[1]) {
+        *msg = "voxel grid spans more than 2^21 cells on an axis (or non-finite points)";
+        return ICPMI_ERR_ARG;
+    }
+    const unsigned runs = runs_flag[0];
+    if ((int64_t)runs > out_cap) {
+        *msg = "output holds fewer rows than the filter yields";
+        return ICPMI_ERR_CAPACITY;
+    }
+    VOX_TRY(exclusive_sum_u32(vs.tmp->p, &b3, counts, offsets, runs, s));
+    hipLaunchKernelGGL(k_voxel_centroids, dim3((runs + 3) / 4), dim3(256), 0, s, d_pts, (const unsigned *)order,
+                       (const unsigned *)offsets, (const unsigned *)counts, (int)runs, d_out);
+    VOX_TRY(hipGetLastError());
+    if (finish) VOX_TRY(hipStreamSynchronize(s));
+    *n_out = runs;
+    return ICPMI_OK;
+#undef VOX_TRY
+}
+
 int voxel_downsample_device(icpmi_ctx *ctx, const double *d_pts, int n, double voxel, double *d_out,
                             int64_t out_cap, int64_t *n_out, bool finish = true)
 {
     hipStream_t s = ctx->stream;
-    int rc;
     if (!(voxel > 0.0)) { // file_utils.cpp:152: returns the input unchanged
         if (out_cap < n) return fail(ctx, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %d", (long long)out_cap, n);
         HIP_TRY(ctx, hipMemcpyAsync(d_out, d_pts, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, s));
@@ -1010,45 +1088,11 @@ int voxel_downsample_device(icpmi_ctx *ctx, const double *d_pts, int n, double v
         *n_out = n;
         return ICPMI_OK;
     }
-    // key origin from the bounding box, formed on the device (k_voxel_keys)
-    const int bblocks = std::max(1, std::min(256, (n + 255) / 256));
-    if ((rc = reserve(ctx, ctx->bbox_part, sizeof(double) * 6 * (size_t)bblocks))) return rc;
-    if ((rc = reserve(ctx, ctx->nn_misc, 256))) return rc;
-    VoxelBox *box = (VoxelBox *)((char *)ctx->nn_misc.p + 192); // (offset 0 is the search's own frame of the target)
-    static_assert(sizeof(VoxelBox) == sizeof(NnFrame) && sizeof(VoxelBox) <= 64, "k_bbox_final writes an NnFrame here");
-    hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_pts, n, (double *)ctx->bbox_part.p, 0);
-    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, (NnFrame *)box);
-    // keys_in | keys_out | unique ; vals_in | order | counts | offsets | runs, flag
-    const size_t un = (size_t)n;
-    if ((rc = reserve(ctx, ctx->vox_keys, sizeof(unsigned long long) * 3 * un))) return rc;
-    if ((rc = reserve(ctx, ctx->vox_vals, sizeof(unsigned) * (4 * un + 16)))) return rc;
-    unsigned long long *keys_in = (unsigned long long *)ctx->vox_keys.p, *keys_out = keys_in + un, *uniq = keys_in + 2 * un;
-    unsigned *vals_in = (unsigned *)ctx->vox_vals.p, *order = vals_in + un, *counts = vals_in + 2 * un,
-             *offsets = vals_in + 3 * un, *runs_d = vals_in + 4 * un;
-    size_t b1 = 0, b2 = 0, b3 = 0;
-    HIP_TRY(ctx, sort_pairs_u64(nullptr, &b1, keys_in, keys_out, vals_in, order, (unsigned)n, s));
-    HIP_TRY(ctx, run_lengths_u64(nullptr, &b2, keys_out, (unsigned)n, uniq, counts, runs_d, s));
-    HIP_TRY(ctx, exclusive_sum_u32(nullptr, &b3, counts, offsets, (unsigned)n, s));
-    size_t tmp_bytes = std::max(b1, std::max(b2, b3));
-    if ((rc = reserve(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
-    hipLaunchKernelGGL(k_voxel_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_pts, n, voxel, (const VoxelBox *)box, runs_d + 1,
-                       keys_in, vals_in);
-    HIP_TRY(ctx, sort_pairs_u64(ctx->sort_tmp.p, &b1, keys_in, keys_out, vals_in, order, (unsigned)n, s));
-    HIP_TRY(ctx, run_lengths_u64(ctx->sort_tmp.p, &b2, keys_out, (unsigned)n, uniq, counts, runs_d, s));
-    unsigned runs_flag[2] = {0, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(runs_flag, runs_d, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s)); // the call's one round trip
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (runs_flag[1])
-        return fail(ctx, ICPMI_ERR_ARG, "voxel grid spans more than 2^21 cells on an axis (or non-finite points)");
-    const unsigned runs = runs_flag[0];
-    if ((int64_t)runs > out_cap) return fail(ctx, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %u", (long long)out_cap, runs);
-    HIP_TRY(ctx, exclusive_sum_u32(ctx->sort_tmp.p, &b3, counts, offsets, runs, s));
-    hipLaunchKernelGGL(k_voxel_centroids, dim3((runs + 3) / 4), dim3(256), 0, s, d_pts, (const unsigned *)order,
-                       (const unsigned *)offsets, (const unsigned *)counts, (int)runs, d_out);
-    HIP_TRY(ctx, hipGetLastError());
-    if (finish) HIP_TRY(ctx, hipStreamSynchronize(s));
-    *n_out = runs;
-    return ICPMI_OK;
+    // (the box sits at offset 192 of nn_misc: offset 0 is the search's own frame of the target)
+    const VoxelScratch vs{&ctx->bbox_part, &ctx->nn_misc, &ctx->vox_keys, &ctx->vox_vals, &ctx->sort_tmp, 192};
+    const char *msg = "";
+    const int rc = voxel_filter_core(s, vs, d_pts, n, voxel, d_out, out_cap, n_out, finish, &msg);
+    return rc == ICPMI_OK ? rc : fail(ctx, rc, "%s", msg);
 }
 
 // update_occupancy_grid (slam_node.cpp:211-221) on device memory: keys of the new points behind the
@@ -1211,6 +1255,8 @@ void icpmi_destroy(icpmi_ctx *ctx)
         if (pf->stream) (void)hipStreamDestroy(pf->stream);
         for (int k = 0; k < 2; ++k)
             if (pf->slot_done[k]) (void)hipEventDestroy(pf->slot_done[k]);
+        for (DevBuf *b : {&pf->filtered[0], &pf->filtered[1], &pf->sc_bbox, &pf->sc_box, &pf->sc_keys, &pf->sc_vals, &pf->sc_tmp})
+            release(*b);
         delete pf;
         ctx->prefetch = nullptr;
     }
@@ -1729,24 +1775,49 @@ int icpmi_stream_reset(icpmi_ctx *ctx)
     return ICPMI_OK;
 }
 
-int icpmi_stream_push(icpmi_ctx *ctx, const double *d_raw_xyz, int64_t n_raw, double voxel_size, int64_t min_points,
-                      const icpmi_config *cfg, icpmi_result *result, double *error_history, int32_t history_cap,
+namespace {
+int stream_check_args(icpmi_ctx *ctx, const icpmi_config *cfg, icpmi_result *result, double *error_history, int32_t history_cap,
                       icpmi_stream_info *info)
 {
-    int rc;
-    if ((rc = check_common(ctx))) return rc;
-    if (!d_raw_xyz || !cfg || !result || !error_history || !info) return fail(ctx, ICPMI_ERR_NULL, "null argument");
-    if (n_raw <= 0 || n_raw > 700000000) return fail(ctx, ICPMI_ERR_ARG, "n_raw out of range");
+    if (!cfg || !result || !error_history || !info) return fail(ctx, ICPMI_ERR_NULL, "null argument");
     if (cfg->max_iterations < 0) return fail(ctx, ICPMI_ERR_ARG, "max_iterations < 0");
     if (history_cap < cfg->max_iterations + 1)
         return fail(ctx, ICPMI_ERR_CAPACITY, "error_history holds %d entries, needs %d", history_cap, cfg->max_iterations + 1);
     memset(result, 0, sizeof(*result));
     for (int i = 0; i < 16; ++i) result->transformation[i] = (i % 5 == 0) ? 1.0 : 0.0;
     memset(info, 0, sizeof(*info));
+    return ICPMI_OK;
+}
+int stream_register(icpmi_ctx *ctx, int64_t n_cur, int64_t min_points, const icpmi_config *cfg, icpmi_result *result,
+                    double *error_history, int32_t history_cap, icpmi_stream_info *info);
+} // namespace
+
+int icpmi_stream_push(icpmi_ctx *ctx, const double *d_raw_xyz, int64_t n_raw, double voxel_size, int64_t min_points,
+                      const icpmi_config *cfg, icpmi_result *result, double *error_history, int32_t history_cap,
+                      icpmi_stream_info *info)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!d_raw_xyz) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (n_raw <= 0 || n_raw > 700000000) return fail(ctx, ICPMI_ERR_ARG, "n_raw out of range");
+    if ((rc = stream_check_args(ctx, cfg, result, error_history, history_cap, info))) return rc;
+    if (ctx->prefetch) { // what the worker filters the next file with
+        std::lock_guard<std::mutex> lk(ctx->prefetch->mu);
+        ctx->prefetch->voxel_hint = voxel_size;
+    }
     // curr = voxel_downsample(raw)  (slam_node.cpp:122), into the buffer that is not the previous frame
     if ((rc = reserve(ctx, ctx->stream_cur, sizeof(double) * 3 * (size_t)n_raw))) return rc;
     int64_t n_cur = 0;
     if ((rc = voxel_downsample_device(ctx, d_raw_xyz, (int)n_raw, voxel_size, (double *)ctx->stream_cur.p, n_raw, &n_cur, false))) return rc;
+    return stream_register(ctx, n_cur, min_points, cfg, result, error_history, history_cap, info);
+}
+
+namespace {
+// everything of a push behind the filter: ctx->stream_cur holds the n_cur rows of the filtered scan
+int stream_register(icpmi_ctx *ctx, int64_t n_cur, int64_t min_points, const icpmi_config *cfg, icpmi_result *result,
+                    double *error_history, int32_t history_cap, icpmi_stream_info *info)
+{
+    int rc;
     info->n_filtered = n_cur;
     info->n_target = ctx->stream_prev_n < 0 ? 0 : ctx->stream_prev_n;
     ctx->stream_cur_n = n_cur;
@@ -1777,6 +1848,7 @@ int icpmi_stream_push(icpmi_ctx *ctx, const double *d_raw_xyz, int64_t n_raw, do
     ctx->stream_prev_n = n_cur;
     return ICPMI_OK;
 }
+} // namespace
 
 namespace {
 bool is_bin(const char *path)
@@ -1797,6 +1869,7 @@ void prefetch_worker(FilePrefetch *pf)
         const int slot = pf->ready[0].empty() ? 0 : (pf->ready[1].empty() ? 1 : (pf->ready_seq[0] < pf->ready_seq[1] ? 0 : 1));
         pf->ready[slot].clear();
         const bool wait_for_push = pf->slot_used[slot];
+        const double voxel = pf->voxel_hint;
         lk.unlock();
         if (wait_for_push) (void)hipEventSynchronize(pf->slot_done[slot]);
         bool ok = false;
@@ -1834,6 +1907,17 @@ void prefetch_worker(FilePrefetch *pf)
                                            (const float *)pf->d_f32[slot], (int)n, 4, pf->d_raw[slot]);
                         // the points are on the device before the file is announced: the push needs no event
                         ok = hipStreamSynchronize(pf->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+                        pf->filtered_voxel[slot] = 0.0;
+                        if (ok && voxel > 0.0 && reserve_raw(pf->filtered[slot], sizeof(double) * 3 * (size_t)n) == hipSuccess) {
+                            const VoxelScratch vs{&pf->sc_bbox, &pf->sc_box, &pf->sc_keys, &pf->sc_vals, &pf->sc_tmp, 0};
+                            const char *msg = "";
+                            int64_t nf = 0;
+                            if (voxel_filter_core(pf->stream, vs, pf->d_raw[slot], (int)n, voxel, (double *)pf->filtered[slot].p, n, &nf,
+                                                  true, &msg) == ICPMI_OK) {
+                                pf->filtered_n[slot] = nf;
+                                pf->filtered_voxel[slot] = voxel;
+                            } // (otherwise the push filters the raw points itself and reports what is wrong with them)
+                        }
                     }
                 }
             }
@@ -1900,8 +1984,19 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
             const int64_t n = pf->ready_n[slot];
             // the slot stays marked as holding this path while the push reads it: the worker takes the other one
             lk.unlock();
-            const int rc2 = icpmi_stream_push(ctx, pf->d_raw[slot], n, voxel_size, min_points, cfg, result, error_history,
-                                              history_cap, info);
+            int rc2;
+            if (pf->filtered_voxel[slot] > 0.0 && pf->filtered_voxel[slot] == voxel_size) {
+                // the worker filtered it too: its buffer becomes the current scan (ours goes to the worker in exchange;
+                // it holds the scan before the previous one, which nothing reads any more)
+                if ((rc2 = stream_check_args(ctx, cfg, result, error_history, history_cap, info)) == ICPMI_OK) {
+                    std::swap(ctx->stream_cur, pf->filtered[slot]);
+                    rc2 = stream_register(ctx, pf->filtered_n[slot], min_points, cfg, result, error_history, history_cap, info);
+                }
+                std::lock_guard<std::mutex> lk2(pf->mu);
+                pf->voxel_hint = voxel_size;
+            } else {
+                rc2 = icpmi_stream_push(ctx, pf->d_raw[slot], n, voxel_size, min_points, cfg, result, error_history, history_cap, info);
+            }
             if (!pf->slot_done[slot]) (void)hipEventCreateWithFlags(&pf->slot_done[slot], hipEventDisableTiming);
             const bool recorded = pf->slot_done[slot] && hipEventRecord(pf->slot_done[slot], ctx->stream) == hipSuccess;
             if (!recorded) (void)hipStreamSynchronize(ctx->stream); // (then the slot is simply free)
