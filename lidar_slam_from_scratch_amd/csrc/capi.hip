@@ -135,6 +135,7 @@ struct FilePrefetch {
     unsigned long long ready_seq[2] = {0, 0}, seq = 0; // which pending file is the older one
     hipEvent_t slot_done[2] = {nullptr, nullptr};      // recorded on the context's stream behind the push that read a slot
     bool slot_used[2] = {false, false};                // ... if any push has read it yet
+    int taking = -1;                                   // the slot a push is reading right now: never the worker's choice
     hipStream_t stream = nullptr;
     bool busy = false, quit = false;
     int device = 0;
@@ -1866,7 +1867,8 @@ void prefetch_worker(FilePrefetch *pf)
         const std::string path = pf->want;
         // the slot to fill: an empty one, else the older of two files that were prefetched but never pushed.  A push
         // may have read the slot: its kernels are behind the event it recorded (another stream than this thread's)
-        const int slot = pf->ready[0].empty() ? 0 : (pf->ready[1].empty() ? 1 : (pf->ready_seq[0] < pf->ready_seq[1] ? 0 : 1));
+        const int slot = pf->taking >= 0 ? 1 - pf->taking
+                                         : (pf->ready[0].empty() ? 0 : (pf->ready[1].empty() ? 1 : (pf->ready_seq[0] < pf->ready_seq[1] ? 0 : 1)));
         pf->ready[slot].clear();
         const bool wait_for_push = pf->slot_used[slot];
         const double voxel = pf->voxel_hint;
@@ -1982,7 +1984,7 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
         const int slot = pf->ready[0] == path ? 0 : (pf->ready[1] == path ? 1 : -1);
         if (slot >= 0) {
             const int64_t n = pf->ready_n[slot];
-            // the slot stays marked as holding this path while the push reads it: the worker takes the other one
+            pf->taking = slot; // the worker fills the other one meanwhile
             lk.unlock();
             int rc2;
             if (pf->filtered_voxel[slot] > 0.0 && pf->filtered_voxel[slot] == voxel_size) {
@@ -2003,6 +2005,7 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
             lk.lock();
             pf->slot_used[slot] = recorded;
             pf->ready[slot].clear(); // free for the worker, behind the event
+            pf->taking = -1;
             lk.unlock();
             return rc2;
         }

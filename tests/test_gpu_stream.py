@@ -210,7 +210,19 @@ def test_prefetched_frames_give_the_same_stream(tmp_path):
     ctx.stream_prefetch_file(paths[3])                       # twice: the second waits for the first
     r3, _, _ = ctx.stream_push_file(paths[3], 0.5, 1000, cfg)
     assert r3.num_iterations == a.iterations[2]
-    ctx.stream_prefetch_file(paths[4])                       # left pending: close() must stop the worker
+    # two files ahead, then three (the oldest gives way and is read by its own push), in stream order throughout
+    ctx.stream_prefetch_file(paths[4])
+    ctx.stream_prefetch_file(paths[5])
+    got = [ctx.stream_push_file(paths[k], 0.5, 1000, cfg)[0].num_iterations for k in (4, 5)]
+    ctx.stream_prefetch_file(paths[6])
+    ctx.stream_prefetch_file(paths[7])
+    ctx.stream_prefetch_file(paths[8])
+    got += [ctx.stream_push_file(paths[k], 0.5, 1000, cfg)[0].num_iterations for k in (6, 7, 8)]
+    # a push with another voxel size than the worker filtered with: the raw points in the slot are filtered by the push
+    ctx.stream_prefetch_file(paths[9])
+    r9, _, i9 = ctx.stream_push_file(paths[9], 0.25, 1000, cfg)
+    assert got == a.iterations[3:8] and i9.status == capi.STREAM_REGISTERED and i9.n_filtered > 1.5 * i1.n_filtered
+    ctx.stream_prefetch_file(paths[10])                      # left pending: close() must stop the worker
     ctx.close()
 
 
