@@ -167,6 +167,27 @@ def test_load_cloud_kitti_bin_and_ply(tmp_path, lib):
     assert capi.load_cloud(str(empty)).shape == (0, 3)
 
 
+def test_bin_to_ply_is_the_converter_tool(tmp_path, lib):
+    """tools/convert_to_ply.cpp:14-68 (convertFile): the PLY written from a KITTI .bin carries the header the tool
+    writes and the records as they are (a trailing partial record dropped), and loads back to the .bin's points."""
+    rng = np.random.default_rng(9)
+    rec = rng.normal(0, 30, (777, 4)).astype(np.float32)
+    kitti = tmp_path / "000007.bin"
+    kitti.write_bytes(rec.tobytes() + b"\x01\x02\x03\x04\x05")       # 5 stray bytes: not a whole record
+    ply = tmp_path / "000007.ply"
+    assert capi.bin_to_ply(str(kitti), str(ply)) == 777
+    raw = ply.read_bytes()
+    header = (b"ply\nformat binary_little_endian 1.0\nelement vertex 777\nproperty float x\nproperty float y\n"
+              b"property float z\nproperty float intensity\nend_header\n")                    # convert_to_ply.cpp:46-55
+    assert raw.startswith(header) and raw[len(header):] == rec.tobytes()
+    assert (capi.load_cloud(str(ply)) == capi.load_cloud(str(kitti))).all()
+    empty = tmp_path / "e.bin"
+    empty.write_bytes(b"")
+    assert capi.bin_to_ply(str(empty), str(tmp_path / "e.ply")) == 0 and capi.load_cloud(str(tmp_path / "e.ply")).shape == (0, 3)
+    with pytest.raises(capi.IcpError):
+        capi.bin_to_ply(str(tmp_path / "missing.bin"), str(tmp_path / "m.ply"))
+
+
 def test_hip_runtime_guard_parses_maps():
     """capi.hip_runtimes_mapped: distinct libamdhip64 images in a /proc/self/maps listing."""
     maps = (
