@@ -278,6 +278,10 @@ int icpmi_occupancy_update_device(icpmi_ctx *ctx, const double *d_world_xyz, int
  * cells_to_occupancy_grid_msg (slam_node.cpp:279-297) rasterises. */
 int icpmi_occupancy_cells(icpmi_ctx *ctx, int32_t *cells_xy, int64_t cap_cells, int64_t *n_cells);
 int icpmi_occupancy_clear(icpmi_ctx *ctx);   /* occupied_cells_.clear() (slam_node.cpp:224) */
+/* The filtered scan the last icpmi_stream_push* left resident (`curr`, slam_node.cpp:122), copied to the host:
+ * what the node hands to loop_detector_.addFrame and keeps in downsampled_clouds_ (:160).  out_xyz may be
+ * NULL (only *n_out is set).  The stream itself never needs this copy. */
+int icpmi_stream_current_scan(icpmi_ctx *ctx, double *out_xyz, int64_t cap, int64_t *n_out);
 /* Both steps on the scan the last icpmi_stream_push* left resident (it never came to the host):
  * pose = new_pose, row-major 4 x 4.  world_out (host, may be NULL) receives the n_filtered x 3 world
  * points (what publish_current_scan sends, :155), *n_world their number; grid may be NULL (no grid

@@ -486,6 +486,15 @@ public:
         if (n_cells) *n_cells = static_cast<std::size_t>(nc);
         return PointCloud(std::move(world));
     }
+    // `curr` (slam_node.cpp:122) of the frame just pushed, for what the node does with it on the host (:160)
+    PointCloud current_scan() const
+    {
+        int64_t n = static_cast<int64_t>(last_filtered_);
+        std::vector<double> xyz(3 * last_filtered_);
+        const int rc = icpmi_stream_current_scan(ctx_->get(), xyz.data(), n, &n);
+        if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx_->get()));
+        return PointCloud(std::move(xyz));
+    }
     void reset() { icpmi_stream_reset(ctx_->get()); }
 
 private:

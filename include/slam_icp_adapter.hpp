@@ -173,6 +173,17 @@ struct OdometryStream {
             return PointCloud::Matrix(0, 3);
         return world;
     }
+    // `curr` of the frame just pushed (slam_node.cpp:122), for loop_detector_.addFrame(curr, frame_idx) and
+    // downsampled_clouds_ (:160): the one thing of the stream the node still wants on the host
+    PointCloud::Matrix current_scan() const
+    {
+        icpmi_ctx *ctx = icp_mi355x_detail::context();
+        PointCloud::Matrix out(last_filtered_ > 0 ? last_filtered_ : 0, 3);
+        int64_t n = 0;
+        if (!ctx || last_filtered_ <= 0 || icpmi_stream_current_scan(ctx, out.data(), static_cast<int64_t>(out.rows()), &n) != ICPMI_OK)
+            return PointCloud::Matrix(0, 3);
+        return out;
+    }
     // the occupied cells as (x, y) pairs, sorted by x then y (occupied_cells_, slam_node.hpp:151)
     std::vector<std::pair<int, int>> occupied_cells() const
     {

@@ -26,7 +26,7 @@ EXPORTS = [
     "icpmi_upload_points_f32", "icpmi_discover_frames", "icpmi_estimate_normals_rows",
     "icpmi_stream_push", "icpmi_stream_push_host", "icpmi_stream_push_file", "icpmi_stream_prefetch_file", "icpmi_stream_reset",
     "icpmi_grid_config_default", "icpmi_occupancy_update", "icpmi_occupancy_update_device", "icpmi_occupancy_cells",
-    "icpmi_occupancy_clear", "icpmi_stream_map_update",
+    "icpmi_occupancy_clear", "icpmi_stream_map_update", "icpmi_stream_current_scan",
     "icpmi_reset_profile", "icpmi_get_profile",
 ]
 
@@ -181,6 +181,7 @@ def load_library(path=None):
     L.icpmi_occupancy_cells.argtypes = [vp, C.POINTER(C.c_int32), C.c_int64, i64p]
     L.icpmi_occupancy_clear.argtypes = [vp]
     L.icpmi_stream_map_update.argtypes = [vp, dp, C.POINTER(GridConfig), dp, C.c_int64, i64p, i64p]
+    L.icpmi_stream_current_scan.argtypes = [vp, dp, C.c_int64, i64p]
     L.icpmi_scan_context.argtypes = [vp, dp, C.c_int64, dp]
     L.icpmi_scan_context_distances.argtypes = [vp, dp, dp, C.c_int64, dp]
     L.icpmi_comm_unique_id.argtypes = [vp, vp]
@@ -453,6 +454,15 @@ class Context:
 
     def occupancy_clear(self):
         self._check(self._lib.icpmi_occupancy_clear(self._h))
+
+    def stream_current_scan(self):
+        """the filtered scan the last stream_push* left resident (slam_node.cpp:122's `curr`), N x 3 fp64"""
+        n = C.c_int64(0)
+        self._check(self._lib.icpmi_stream_current_scan(self._h, None, 0, C.byref(n)))
+        out = np.empty((n.value, 3))
+        if n.value:
+            self._check(self._lib.icpmi_stream_current_scan(self._h, _dp(out), n.value, C.byref(n)))
+        return out
 
     def stream_map_update(self, pose, grid=None, want_world=True, update_grid=True, n_rows=None):
         """slam_node.cpp:147-153 on the scan the last stream_push* left resident: (world points or None, cells in the set).

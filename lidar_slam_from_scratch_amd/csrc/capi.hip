@@ -2146,6 +2146,22 @@ int icpmi_occupancy_clear(icpmi_ctx *ctx)
     return ICPMI_OK;
 }
 
+int icpmi_stream_current_scan(icpmi_ctx *ctx, double *out_xyz, int64_t cap, int64_t *n_out)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!n_out) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (ctx->stream_prev_n < 0) return fail(ctx, ICPMI_ERR_ARG, "no resident frame: call icpmi_stream_push first");
+    *n_out = ctx->stream_prev_n;
+    if (!out_xyz || ctx->stream_prev_n == 0) return ICPMI_OK;
+    if (cap < ctx->stream_prev_n)
+        return fail(ctx, ICPMI_ERR_CAPACITY, "output holds %lld rows, needs %lld", (long long)cap, (long long)ctx->stream_prev_n);
+    HIP_TRY(ctx, hipMemcpyAsync(out_xyz, ctx->stream_prev.p, sizeof(double) * 3 * (size_t)ctx->stream_prev_n, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ICPMI_OK;
+}
+
 int icpmi_stream_map_update(icpmi_ctx *ctx, const double pose[16], const icpmi_grid_config *grid, double *world_out,
                             int64_t world_cap, int64_t *n_world, int64_t *n_cells)
 {

@@ -19,8 +19,9 @@ int main()
     icpmi_grid_config_default(&grid);
     slam::PointCloud::Matrix world = stream.map_update(slam::Transformation::identity(), &grid);
     std::vector<std::pair<int, int>> cells = stream.occupied_cells();
+    slam::PointCloud::Matrix curr = stream.current_scan();
     stream.reset();
-    return (r.converged || s.registered || v.rows() > 0 || world.rows() > 0 || !cells.empty()) ? 1 : 0;
+    return (r.converged || s.registered || v.rows() > 0 || world.rows() > 0 || !cells.empty() || curr.rows() > 0) ? 1 : 0;
 }
 #else
 #error "adapter_check: <Eigen/Dense> or slam_viz/core/types.hpp not found -- nothing to check here"

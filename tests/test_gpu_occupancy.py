@@ -103,6 +103,7 @@ def test_stream_map_update_is_the_map_side_of_process_frame(tmp_path, oracle):
         world, n_cells = ctx.stream_map_update(pose, grid)
         curr = oracle.voxel_downsample(capi.load_cloud(p), 0.5)
         assert world.shape == curr.shape == (info.n_filtered, 3)
+        assert (ctx.stream_current_scan() == curr).all()          # the resident filtered scan is the oracle's, bit for bit
         R, t = pose[:3, :3], pose[:3, 3]
         ref_world = np.empty_like(curr)
         for a in range(3):                          # ((x r_a0 + y r_a1) + z r_a2) + t_a, the product's index order
