@@ -178,6 +178,8 @@ v = orc.voxel_downsample(np.vstack([src, -src]), 0.5)
 assert 0 < v.shape[0] <= 2 * src.shape[0]
 sc = orc.scan_context(src)
 assert orc.scan_context_distance(sc, sc) < 1e-12
+cells, keep = orc.occupancy_cells(np.vstack([src, [[np.nan, 1, 1], [1e300, 0, 1], [4e8, 4e8, 1], [3, np.inf, 1]]]), [0.3, -0.2, 0.0])
+assert keep[:src.shape[0]].any() and not keep[-4:].any()      # (casts of non-finite / huge quotients must not be reached)
 plane = np.stack([src[:, 0], src[:, 1], 0 * src[:, 2]], axis=1)
 orc.solve_point_to_plane(plane, plane, np.tile([0., 0., 1.], (plane.shape[0], 1)))   # singular 6x6: zero-pivot rule
 print("sanitized oracle ok")
