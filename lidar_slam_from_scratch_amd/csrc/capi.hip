@@ -48,6 +48,8 @@ hipError_t exclusive_sum_u32(void *temp, size_t *temp_bytes, const unsigned *in,
                              hipStream_t stream);
 hipError_t sort_keys_u64(void *temp, size_t *temp_bytes, const unsigned long long *keys_in,
                          unsigned long long *keys_out, unsigned n, hipStream_t stream);
+hipError_t merge_keys_u64(void *temp, size_t *temp_bytes, const unsigned long long *a, const unsigned long long *b,
+                          unsigned long long *out, unsigned na, unsigned nb, hipStream_t stream);
 }
 
 namespace {
@@ -1096,43 +1098,45 @@ int voxel_downsample_device(icpmi_ctx *ctx, const double *d_pts, int n, double v
     return rc == ICPMI_OK ? rc : fail(ctx, rc, "%s", msg);
 }
 
-// update_occupancy_grid (slam_node.cpp:211-221) on device memory: keys of the new points behind the
-// set, one sort, one run-length pass; the set's new size is queued for the host (ctx->h_grid[0]) and
-// picked up by grid_finish after the caller's wait.
+// update_occupancy_grid (slam_node.cpp:211-221) on device memory: the frame's keys, less those the set already
+// holds, sorted, made unique and merged into the set (occupancy.h); the set's new size is queued for the host
+// (ctx->h_grid[0]) and picked up by grid_finish after the caller's wait.
 int grid_update_queue(icpmi_ctx *ctx, const double *d_world, int n, const double sensor[3], const icpmi_grid_config *grid)
 {
     if (!(grid->resolution > 0.0)) return fail(ctx, ICPMI_ERR_ARG, "grid resolution must be positive");
     hipStream_t s = ctx->stream;
     int rc;
-    const size_t total = (size_t)ctx->grid_n + (size_t)n;
+    const size_t set_n = (size_t)ctx->grid_n, total = set_n + (size_t)n;
     if (total > (size_t)2000000000) return fail(ctx, ICPMI_ERR_ARG, "occupancy set too large");
-    if ((rc = reserve(ctx, ctx->grid_in, sizeof(unsigned long long) * std::max<size_t>(total, 1)))) return rc;
-    if ((rc = reserve(ctx, ctx->grid_out, sizeof(unsigned long long) * std::max<size_t>(total, 1)))) return rc;
-    if ((rc = reserve(ctx, ctx->grid_cnt, sizeof(unsigned) * (total + 16)))) return rc;
-    unsigned long long *in = (unsigned long long *)ctx->grid_in.p, *out = (unsigned long long *)ctx->grid_out.p;
-    unsigned *counts = (unsigned *)ctx->grid_cnt.p, *runs_d = counts + total, *count_d = runs_d + 1;
-    size_t b1 = 0, b2 = 0;
-    HIP_TRY(ctx, sort_keys_u64(nullptr, &b1, in, out, (unsigned)total, s));
-    HIP_TRY(ctx, run_lengths_u64(nullptr, &b2, out, (unsigned)total, in, counts, runs_d, s));
-    if ((rc = reserve(ctx, ctx->sort_tmp, std::max(b1, b2)))) return rc;
-    if (ctx->grid_n > 0)
-        HIP_TRY(ctx, hipMemcpyAsync(in, ctx->grid_set.p, sizeof(unsigned long long) * (size_t)ctx->grid_n, hipMemcpyDeviceToDevice, s));
-    if (n > 0) {
-        GridParams g{sensor[0], sensor[1], grid->resolution, grid->height_min, grid->height_max, grid->max_range};
-        hipLaunchKernelGGL(k_grid_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_world, n, g, in + ctx->grid_n);
+    if (n <= 0) { // nothing to insert
+        ctx->h_grid[0] = (unsigned)set_n;
+        return ICPMI_OK;
     }
-    if (total > 0) {
-        HIP_TRY(ctx, sort_keys_u64(ctx->sort_tmp.p, &b1, in, out, (unsigned)total, s));
-        // unique keys -> the new set (grid_set is reallocated only when it must grow)
-        if ((rc = reserve(ctx, ctx->grid_set, sizeof(unsigned long long) * total))) return rc;
-        HIP_TRY(ctx, run_lengths_u64(ctx->sort_tmp.p, &b2, out, (unsigned)total, (unsigned long long *)ctx->grid_set.p, counts,
-                                     runs_d, s));
-        hipLaunchKernelGGL(k_grid_count, dim3(1), dim3(1), 0, s, (const unsigned long long *)ctx->grid_set.p,
-                           (const unsigned *)runs_d, count_d);
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_grid, count_d, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    } else {
-        ctx->h_grid[0] = 0;
-    }
+    const size_t un = (size_t)n;
+    // grid_in: the frame's keys | sorted | unique ; grid_cnt: run lengths | runs, count ; grid_out: the merged set
+    if ((rc = reserve(ctx, ctx->grid_in, sizeof(unsigned long long) * 3 * un))) return rc;
+    if ((rc = reserve(ctx, ctx->grid_cnt, sizeof(unsigned) * (un + 16)))) return rc;
+    if ((rc = reserve(ctx, ctx->grid_out, sizeof(unsigned long long) * total))) return rc;
+    unsigned long long *keys = (unsigned long long *)ctx->grid_in.p, *sorted = keys + un, *uniq = keys + 2 * un;
+    unsigned *counts = (unsigned *)ctx->grid_cnt.p, *runs_d = counts + un, *count_d = runs_d + 1;
+    size_t b1 = 0, b2 = 0, b3 = 0;
+    HIP_TRY(ctx, sort_keys_u64(nullptr, &b1, keys, sorted, (unsigned)n, s));
+    HIP_TRY(ctx, run_lengths_u64(nullptr, &b2, sorted, (unsigned)n, uniq, counts, runs_d, s));
+    HIP_TRY(ctx, merge_keys_u64(nullptr, &b3, (const unsigned long long *)ctx->grid_set.p, uniq, (unsigned long long *)ctx->grid_out.p,
+                                (unsigned)set_n, (unsigned)n, s));
+    if ((rc = reserve(ctx, ctx->sort_tmp, std::max(b1, std::max(b2, b3))))) return rc;
+    GridParams g{sensor[0], sensor[1], grid->resolution, grid->height_min, grid->height_max, grid->max_range};
+    hipLaunchKernelGGL(k_grid_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_world, n, g, keys);
+    if (set_n > 0)
+        hipLaunchKernelGGL(k_grid_drop_known, dim3((n + 255) / 256), dim3(256), 0, s, keys, n,
+                           (const unsigned long long *)ctx->grid_set.p, (int)set_n);
+    HIP_TRY(ctx, sort_keys_u64(ctx->sort_tmp.p, &b1, keys, sorted, (unsigned)n, s));
+    HIP_TRY(ctx, run_lengths_u64(ctx->sort_tmp.p, &b2, sorted, (unsigned)n, uniq, counts, runs_d, s));
+    hipLaunchKernelGGL(k_grid_pad, dim3((n + 255) / 256), dim3(256), 0, s, uniq, n, (const unsigned *)runs_d, (unsigned)set_n, count_d);
+    HIP_TRY(ctx, merge_keys_u64(ctx->sort_tmp.p, &b3, set_n > 0 ? (const unsigned long long *)ctx->grid_set.p : uniq, uniq,
+                                (unsigned long long *)ctx->grid_out.p, (unsigned)set_n, (unsigned)n, s));
+    std::swap(ctx->grid_set, ctx->grid_out); // the merged array (cells, then n - new entries of kGridNone) is the set now
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_grid, count_d, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;
 }

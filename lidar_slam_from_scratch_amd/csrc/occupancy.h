@@ -7,8 +7,11 @@
 //     occupied_cells_.insert({(int)floor(x / resolution), (int)floor(y / resolution)});   :217-219
 // The reference's set is a std::unordered_set<GridCell>; here it is a sorted array of unique 64-bit
 // keys in device memory ((x, y) biased to unsigned, x in the upper half: ascending keys = ascending
-// (x, y)), and an update is key formation, one radix sort of {set, new keys} and a run-length pass.
-// Integer work, HBM-bound: 24 B read + 8 B written per point, then the sort.
+// (x, y)).  An update forms the keys of the frame's points and drops those already in the set (a
+// binary search each), sorts what is left -- a few hundred new cells and a lot of "none" -- makes it
+// unique, and MERGES it into the set: the work per frame follows the frame, not the map (a re-sort of
+// {set, new keys} grew with the drive: 300k cells after a KITTI-length sequence).
+// Integer work, HBM-bound: 24 B read per point, then small sorts and one pass over the set.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -48,13 +51,37 @@ __global__ __launch_bounds__(256) void k_grid_keys(const double *__restrict__ pt
     keys[i] = key;
 }
 
-// after the run-length pass over the sorted keys: the set's size is the number of runs, less the
-// run of kGridNone at the end when there is one
-__global__ void k_grid_count(const unsigned long long *__restrict__ unique, const unsigned *__restrict__ runs,
-                             unsigned *__restrict__ count)
+// keys already in the (sorted, unique) set become kGridNone
+__global__ __launch_bounds__(256) void k_grid_drop_known(unsigned long long *__restrict__ keys, int n,
+                                                         const unsigned long long *__restrict__ set, int set_n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    if (k == kGridNone) return;
+    int lo = 0, hi = set_n; // first position with set[pos] >= k
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (set[mid] < k) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo < set_n && set[lo] == k) keys[i] = kGridNone;
+}
+
+// After the run-length pass over the frame's sorted keys: `unique` holds `*runs` keys, the last of
+// them kGridNone if any point marked nothing or a known cell.  Everything from the first kGridNone on
+// is set to kGridNone (the merge then leaves those n - new entries behind the cells), and the set's
+// size after the merge is published: set_n + new.
+__global__ __launch_bounds__(256) void k_grid_pad(unsigned long long *__restrict__ unique, int n,
+                                                  const unsigned *__restrict__ runs, unsigned set_n,
+                                                  unsigned *__restrict__ count)
 {
     const unsigned r = *runs;
-    *count = r > 0 && unique[r - 1] == kGridNone ? r - 1 : r;
+    const unsigned fresh = r > 0 && unique[r - 1] == kGridNone ? r - 1 : r;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    // (the read of unique[r - 1] above and the writes below touch the same word only with the same value)
+    if (i < n && (unsigned)i >= fresh) unique[i] = kGridNone;
+    if (i == 0) *count = set_n + fresh;
 }
 
 __global__ __launch_bounds__(256) void k_grid_decode(const unsigned long long *__restrict__ keys, int n,

@@ -46,6 +46,16 @@ hipError_t sort_keys_u64(void *temp, size_t *temp_bytes, const unsigned long lon
     return rocprim::radix_sort_keys(temp, *temp_bytes, keys_in, keys_out, n, 0u, 64u, stream);
 }
 
+} // namespace icpmi
+#include <rocprim/device/device_merge.hpp>
+namespace icpmi {
+// two sorted key arrays -> one (the occupancy set and a frame's new cells)
+hipError_t merge_keys_u64(void *temp, size_t *temp_bytes, const unsigned long long *a, const unsigned long long *b,
+                          unsigned long long *out, unsigned na, unsigned nb, hipStream_t stream)
+{
+    return rocprim::merge(temp, *temp_bytes, a, b, out, na, nb, rocprim::less<unsigned long long>(), stream);
+}
+
 hipError_t exclusive_sum_u32(void *temp, size_t *temp_bytes, const unsigned *in, unsigned *out, unsigned n,
                              hipStream_t stream)
 {
