@@ -123,12 +123,25 @@ def test_cpp_adapter_compiles_against_a_minimal_cloud_type(tmp_path):
         "       nn.find_correspondences(a, mt, d); nn.tree().nearest({0.0, 0.0, 0.0}); } catch (const std::exception&) { }\n"
         " try { icp_mi355x::estimate_normals(b, 20); } catch (const std::exception&) { }\n"
         " try { icp_mi355x::solve_point_to_plane(a, b, b); } catch (const std::exception&) { }\n"
+        " // ... and the frame step, the map side and loop closure\n"
+        " try { icp_mi355x::OdometryStream st; st.prefetch_file(\"x.bin\"); auto s1 = st.push(a, 0.5, 1000, c);\n"
+        "       auto s2 = st.push_file(\"x.bin\", 0.5, 1000, c); icp_mi355x::OccupancyGridConfig g; std::size_t nc = 0;\n"
+        "       auto w = st.map_update(icp_mi355x::Transformation(), &g, &nc); auto cur = st.current_scan(); st.reset();\n"
+        "       (void)s1; (void)s2; (void)w; (void)cur; } catch (const std::exception&) { }\n"
+        " try { icp_mi355x::OccupancyGrid og; og.update(a, {0.0, 0.0, 0.0}); auto r = og.raster(); og.clear(); (void)r; }\n"
+        " catch (const std::exception&) { }\n"
+        " try { icp_mi355x::LoopClosureDetector det; det.addFrame(a, 0); auto f = det.detect();\n"
+        "       auto sc = icp_mi355x::ScanContext::compute(a); (void)sc.distance(sc); (void)f; } catch (const std::exception&) { }\n"
         " return 0; }\n")
     exe = tmp_path / "t"
     subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src),
                            "-o", str(exe), build.LIB_PATH, "-Wl,-rpath," + os.path.dirname(build.LIB_PATH),
                            "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"])
     assert subprocess.call([str(exe)]) == 0
+    # the three demo programs the GPU tests run must at least compile here
+    for demo in ("mirror_demo.cpp", "stream_demo.cpp", "loop_demo.cpp"):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", demo)])
 
 
 def test_load_cloud_kitti_bin_and_ply(tmp_path, lib):
