@@ -1710,11 +1710,17 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             }
         }
     }
-    for (int e = 128 * kPairs + lane; e < nloc; e += 64) {
-        const unsigned v = mine16[gslot(e)];
-        if (v < lmin16) {
-            lmin16 = v;
-            lslot = e;
+    // slots beyond the register-resident ones (> 106k targets): pairs again, dword loads, four in flight
+#pragma unroll 4
+    for (int e = 128 * kPairs + 2 * lane; e < nloc; e += 128) { // (nloc is a multiple of 32: e + 1 < nloc)
+        const unsigned w = *reinterpret_cast<const unsigned *>(mine16 + gslot(e));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned v = h ? w >> 16 : w & 0xFFFFu;
+            if (v < lmin16) {
+                lmin16 = v;
+                lslot = e + h;
+            }
         }
     }
     const float lmin = __uint_as_float(lmin16 << 16);
@@ -1878,10 +1884,15 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
             list_flagged(act, 2 * lane + 128 * (u >> 1) + (u & 1));
         }
 #pragma unroll 1
-        for (int e0 = 128 * kPairs; e0 < nloc; e0 += 64) { // slots beyond the register-resident ones (> 106k targets)
-            const int e = e0 + lane;
-            const bool cand = e < nloc && e != bslot && mine(gslot(e)) <= tall;
-            if (__ballot(cand)) list_flagged(cand, e);
+        for (int e0 = 128 * kPairs; e0 < nloc; e0 += 128) { // slots beyond the register-resident ones (> 106k targets)
+            const int e = e0 + 2 * lane;
+            const unsigned w = e < nloc ? *reinterpret_cast<const unsigned *>(mine16 + gslot(e)) : 0x7F617F61u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned v = h ? w >> 16 : w & 0xFFFFu;
+                const bool cand = e + h < nloc && e + h != bslot && v <= tall16;
+                if (__ballot(cand)) list_flagged(cand, e + h);
+            }
         }
 #if defined(ICPMI_KNN_STOP) && ICPMI_KNN_STOP == 4
         nf_last = nf, attempts_run = attempt + 1;
