@@ -594,7 +594,10 @@ def test_nonfinite_input_is_memory_safe(gpu_ctx):
     assert np.isfinite(res.final_error)                 # the context still works
 
 
-@pytest.mark.parametrize("m,k", [(700, 5), (700, 20), (12000, 1), (12000, 20), (12000, 32), (12000, 40)])
+# (110,000 and 300,000 targets: more slot minima per row than a lane keeps in registers -- 1,664 slots = 106,496
+#  targets --, so the k-NN resolve's tail loops run: half a trip at 110k, 24 trips at 300k)
+@pytest.mark.parametrize("m,k", [(700, 5), (700, 20), (12000, 1), (12000, 20), (12000, 32), (12000, 40),
+                                 (110000, 20), (300000, 20)])
 def test_k_nearest_matches_oracle(gpu_ctx, oracle, m, k):
     """icpmi_k_nearest = KDTree::k_nearest (kdtree.hpp:65-78) for a batch: closest first, the query
     point itself included when it is a target (distance 0).  Against the oracle's kd-tree k-NN
