@@ -457,6 +457,20 @@ int resolve_waves(int n)
     // per wave need a second round at 5 per SIMD) -- and lost: the longer chain per wave costs more
     return n <= ICPMI_RESOLVE_Q32_FROM ? 0 : -32;
 }
+// All-pairs coarse pass on few units (filtered scans: 14 query blocks x 4 splits): 256-query units -- one
+// 32-query tile per wave instead of two -- when even those fit the chip in one round.  The units' time is
+// their waves' time there, so half the work per wave is a shorter pass; once the chip is full the 512-query
+// unit amortises its staging and operand build over twice the results.  ICPMI_COARSE_HALF_UNITS=<units> moves
+// the switch (0: never).
+bool coarse_half_units(const icpmi_ctx *ctx, int n, int splits)
+{
+    static const long limit = [] {
+        const char *e = getenv("ICPMI_COARSE_HALF_UNITS");
+        return e ? atol(e) : -1l;
+    }();
+    const long units = (long)((n + kCoarseQueries - 1) / kCoarseQueries) * splits;
+    return units <= (limit >= 0 ? limit : (long)ctx->cu_count);
+}
 int resolve_blocks(int n)
 {
     const int w = resolve_waves(n);
@@ -501,6 +515,11 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
                                (const unsigned *)ctx->work.p, (const unsigned *)(cnt + (pruned_pass & 1)),
                                cnt + ((pruned_pass + 1) & 1),
                                (unsigned)(((n + kCoarseQueries - 1) / kCoarseQueries) * splits), counters + 2, st);
+        } else if (coarse_half_units(ctx, n, splits)) {
+            constexpr int per = kCoarseQueries / kCoarseQT; // queries per workgroup with one tile per wave
+            hipLaunchKernelGGL((k_nn_coarse<0, 1, kCoarseWaves>), dim3((n + per - 1) / per, splits), dim3(kCoarseThreads), 0,
+                               ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames, (float2 *)ctx->coarse.p,
+                               (float *)nullptr, st);
         } else {
             hipLaunchKernelGGL((k_nn_coarse<0, kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
                                dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,
@@ -618,6 +637,12 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                                    ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots, frames, (const NnFrame *)ctx->nn_misc.p, knn,
                                    fb_list, fb_count, (const int *)blk_cnt, (const int *)blk_list);
             } else {
+                if (coarse_half_units(ctx, nq, splits)) {
+                    constexpr int per = kCoarseQueries / kCoarseQT;
+                    hipLaunchKernelGGL((k_nn_coarse<1, 1, kCoarseWaves>), dim3((nq + per - 1) / per, splits),
+                                       dim3(kCoarseThreads), 0, s, d_qry + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
+                                       frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);
+                } else
                 hipLaunchKernelGGL((k_nn_coarse<1, kCoarseQT, kCoarseWaves>), dim3(nblk, splits),
                                    dim3(kCoarseThreads), 0, s, d_qry + 3 * c0, nq, (const uint4 *)ctx->bpack.p,
                                    frames, (float2 *)nullptr, (float *)ctx->slotmin.p, (const IcpState *)nullptr);

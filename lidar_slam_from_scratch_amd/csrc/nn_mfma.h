@@ -444,11 +444,13 @@ template <int QT, bool QSOA>
 __device__ __forceinline__ void coarse_build_a(uint4 *rows, const int lane, const int q0,
                                                const double *__restrict__ qry, const int n, const size_t qstride,
                                                const double c0, const double c1, const double c2,
-                                               bf16x8 (&afrag)[QT], float (&pn)[QT / 2])
+                                               bf16x8 (&afrag)[QT], float (&pn)[(QT + 1) / 2])
 {
+    static_assert(QT == 1 || QT % 2 == 0, "operands are staged 64 queries at a time (QT = 1: 32, by both half-waves)");
 #pragma unroll
-    for (int gq = 0; gq < QT / 2; ++gq) {
-        const int iq = q0 + gq * 64 + lane < n ? q0 + gq * 64 + lane : n - 1;
+    for (int gq = 0; gq < (QT + 1) / 2; ++gq) {
+        const int ql = QT == 1 ? (lane & 31) : lane; // QT = 1: lanes 32.. repeat the rows of lanes 0..31
+        const int iq = q0 + gq * 64 + ql < n ? q0 + gq * 64 + ql : n - 1;
         const float px = (float)((QSOA ? qry[iq] : qry[3 * iq]) - c0),
                     py = (float)((QSOA ? qry[qstride + iq] : qry[3 * iq + 1]) - c1),
                     pz = (float)((QSOA ? qry[2 * qstride + iq] : qry[3 * iq + 2]) - c2);
@@ -468,11 +470,11 @@ __device__ __forceinline__ void coarse_build_a(uint4 *rows, const int lane, cons
         pn[gq] -= __uint_as_float(pnh << 16);
         const unsigned one = 0x3f80u;
         // slots: x: h h m m, y: h h m m | z: h h m m, 1 1 1 |P|^2
-        rows[lane * 2 + 0] = make_uint4(xh | (xh << 16), xm | (xm << 16), yh | (yh << 16), ym | (ym << 16));
-        rows[lane * 2 + 1] = make_uint4(zh | (zh << 16), zm | (zm << 16), one | (one << 16), one | (pnh << 16));
+        rows[ql * 2 + 0] = make_uint4(xh | (xh << 16), xm | (xm << 16), yh | (yh << 16), ym | (ym << 16));
+        rows[ql * 2 + 1] = make_uint4(zh | (zh << 16), zm | (zm << 16), one | (one << 16), one | (pnh << 16));
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < (QT == 1 ? 1 : 2); ++t) {
             const uint4 f = rows[(t * 32 + (lane & 31)) * 2 + (lane >> 5)];
             afrag[gq * 2 + t] = __builtin_bit_cast(bf16x8, f);
         }
@@ -506,7 +508,7 @@ __device__ __forceinline__ void coarse_tiles(const uint4 *tiles, const int lane,
 // columns 16*(l>>5).. +15; + |P|^2, per-lane top-2, the two halves merge with one cross-lane step.
 template <int MODE, int QT>
 __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const int q0, const int s, const int nsplits,
-                                                const int n, const f32x16 (&m)[QT], const float (&pn)[QT / 2],
+                                                const int n, const f32x16 (&m)[QT], const float (&pn)[(QT + 1) / 2],
                                                 float2 *__restrict__ coarse, float *__restrict__ slotmin)
 {
     const int ql = lane & 31, half = lane >> 5;
@@ -604,7 +606,7 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
     const double c0 = frames[s].c[0], c1 = frames[s].c[1], c2 = frames[s].c[2];
 
     bf16x8 afrag[QT];
-    float pn[QT / 2];
+    float pn[(QT + 1) / 2];
     coarse_build_a<QT, QSOA>(lds + wave * (64 * 2), lane, q0, qry, n, qstride, c0, c1, c2, afrag, pn);
     f32x16 m[QT];
 #pragma unroll
@@ -660,7 +662,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/,
     float *__restrict__ slotmin /*[n][splits*32]*/, const IcpState *__restrict__ st)
 {
-    static_assert(QT % 2 == 0, "operands are staged 64 queries at a time");
     if (st && st->done) return;
     __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
     coarse_unit<MODE, QT, WAVES>(lds, blockIdx.x, blockIdx.y, gridDim.y, qry, n, 0, Bpack, frames, coarse, slotmin);
