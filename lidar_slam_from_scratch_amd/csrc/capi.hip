@@ -9,6 +9,7 @@
 // There is no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <chrono>
 
 #include <dirent.h>
 #include <dlfcn.h>
@@ -148,6 +149,9 @@ struct FilePrefetch {
     int64_t filtered_n[2] = {0, 0};        // ... its rows ...
     double filtered_voxel[2] = {0.0, 0.0}; // ... and the voxel size it was made with (0: not filtered)
     DevBuf sc_bbox, sc_box, sc_keys, sc_vals, sc_tmp;
+    // where the worker's time goes (ICPMI_PREFETCH_STATS=1: printed to stderr when the context is destroyed)
+    double t_wait = 0, t_read = 0, t_upload = 0, t_filter = 0;
+    long files = 0;
 };
 
 struct icpmi_ctx {
@@ -1048,8 +1052,11 @@ struct VoxelScratch {
 };
 
 // No context in here (the worker thread runs it too): a code and a static message come back.
+// `deferred` (the prefetch worker; implies `finish`): nothing waits for the number of voxels in the middle -- the
+// prefix sum runs over all n counts, the centroid kernel is launched for min(n, out_cap) voxels and reads the
+// number itself -- and count and range flag come back behind the centroids, with the call's only wait.
 int voxel_filter_core(hipStream_t s, VoxelScratch vs, const double *d_pts, int n, double voxel, double *d_out, int64_t out_cap,
-                      int64_t *n_out, bool finish, const char **msg)
+                      int64_t *n_out, bool finish, const char **msg, bool deferred = false)
 {
 #define VOX_TRY(call)                                   \
     do {                                                \
@@ -1084,6 +1091,13 @@ int voxel_filter_core(hipStream_t s, VoxelScratch vs, const double *d_pts, int n
     VOX_TRY(sort_pairs_u64(vs.tmp->p, &b1, keys_in, keys_out, vals_in, order, (unsigned)n, s));
     VOX_TRY(run_lengths_u64(vs.tmp->p, &b2, keys_out, (unsigned)n, uniq, counts, runs_d, s));
     unsigned runs_flag[2] = {0, 0};
+    if (deferred) {
+        const int bound = (int)std::min<int64_t>(n, out_cap);
+        VOX_TRY(exclusive_sum_u32(vs.tmp->p, &b3, counts, offsets, (unsigned)n, s));
+        hipLaunchKernelGGL(k_voxel_centroids, dim3((bound + 3) / 4), dim3(256), 0, s, d_pts, (const unsigned *)order,
+                           (const unsigned *)offsets, (const unsigned *)counts, bound, d_out, (const unsigned *)runs_d);
+        VOX_TRY(hipGetLastError());
+    }
     VOX_TRY(hipMemcpyAsync(runs_flag, runs_d, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s)); // the call's one round trip
     VOX_TRY(hipStreamSynchronize(s));
     if (runs_flag[1]) {
@@ -1095,11 +1109,13 @@ int voxel_filter_core(hipStream_t s, VoxelScratch vs, const double *d_pts, int n
         *msg = "output holds fewer rows than the filter yields";
         return ICPMI_ERR_CAPACITY;
     }
-    VOX_TRY(exclusive_sum_u32(vs.tmp->p, &b3, counts, offsets, runs, s));
-    hipLaunchKernelGGL(k_voxel_centroids, dim3((runs + 3) / 4), dim3(256), 0, s, d_pts, (const unsigned *)order,
-                       (const unsigned *)offsets, (const unsigned *)counts, (int)runs, d_out);
-    VOX_TRY(hipGetLastError());
-    if (finish) VOX_TRY(hipStreamSynchronize(s));
+    if (!deferred) {
+        VOX_TRY(exclusive_sum_u32(vs.tmp->p, &b3, counts, offsets, runs, s));
+        hipLaunchKernelGGL(k_voxel_centroids, dim3((runs + 3) / 4), dim3(256), 0, s, d_pts, (const unsigned *)order,
+                           (const unsigned *)offsets, (const unsigned *)counts, (int)runs, d_out);
+        VOX_TRY(hipGetLastError());
+        if (finish) VOX_TRY(hipStreamSynchronize(s));
+    }
     *n_out = runs;
     return ICPMI_OK;
 #undef VOX_TRY
@@ -1277,6 +1293,9 @@ void icpmi_destroy(icpmi_ctx *ctx)
         }
         pf->cv.notify_all();
         if (pf->worker.joinable()) pf->worker.join();
+        if (getenv("ICPMI_PREFETCH_STATS") && pf->files > 0)
+            fprintf(stderr, "prefetch worker, ms per file over %ld files: wait for slot %.4f, open + read (first half on its way) %.4f, queueing %.4f, filter + wait %.4f\n",
+                    pf->files, pf->t_wait / pf->files, pf->t_read / pf->files, pf->t_upload / pf->files, pf->t_filter / pf->files);
         if (pf->h_buf) (void)hipHostFree(pf->h_buf);
         for (int k = 0; k < 2; ++k) {
             if (pf->d_f32[k]) (void)hipFree(pf->d_f32[k]);
@@ -1928,7 +1947,11 @@ void prefetch_worker(FilePrefetch *pf)
         const bool wait_for_push = pf->slot_used[slot];
         const double voxel = pf->voxel_hint;
         lk.unlock();
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double ta = now();
         if (wait_for_push) (void)hipEventSynchronize(pf->slot_done[slot]);
+        const double tb = now();
+        double tc = tb, td = tb, te = tb;
         bool ok = false;
         int64_t n = 0;
         if (FILE *f = fopen(path.c_str(), "rb")) {
@@ -1956,30 +1979,48 @@ void prefetch_worker(FilePrefetch *pf)
                         pf->d_cap[slot] = cap;
                 }
                 if (pf->h_cap >= bytes && pf->d_cap[slot] >= (size_t)n) {
-                    const size_t got = fread(pf->h_buf, 1, bytes, f);
-                    if (got < bytes) memset((char *)pf->h_buf + got, 0, bytes - got); // like the synchronous path
+                    // the file in two parts, the first one on its way to the device while the second is read; then the
+                    // widening and the filter are queued behind the copies and ONE wait ends the file
+                    char *h = (char *)pf->h_buf;
+                    const size_t half = (bytes / 2) / 16 * 16;
+                    const size_t got = fread(h, 1, half, f);
+                    if (got < half) memset(h + got, 0, bytes - got); // a short read leaves zeros, like the synchronous path
                     if (!pf->stream) (void)hipStreamCreateWithFlags(&pf->stream, hipStreamNonBlocking);
-                    if (pf->stream && hipMemcpyAsync(pf->d_f32[slot], pf->h_buf, bytes, hipMemcpyHostToDevice, pf->stream) == hipSuccess) {
+                    bool up = pf->stream && hipMemcpyAsync(pf->d_f32[slot], h, half, hipMemcpyHostToDevice, pf->stream) == hipSuccess;
+                    if (got == half) {
+                        const size_t got2 = fread(h + half, 1, bytes - half, f);
+                        if (got2 < bytes - half) memset(h + half + got2, 0, bytes - half - got2);
+                    }
+                    tc = now();
+                    up = up && hipMemcpyAsync((char *)pf->d_f32[slot] + half, h + half, bytes - half, hipMemcpyHostToDevice, pf->stream) == hipSuccess;
+                    if (up) {
                         hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pf->stream,
                                            (const float *)pf->d_f32[slot], (int)n, 4, pf->d_raw[slot]);
-                        // the points are on the device before the file is announced: the push needs no event
-                        ok = hipStreamSynchronize(pf->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+                        td = now();
                         pf->filtered_voxel[slot] = 0.0;
-                        if (ok && voxel > 0.0 && reserve_raw(pf->filtered[slot], sizeof(double) * 3 * (size_t)n) == hipSuccess) {
+                        bool filtered = false;
+                        int64_t nf = 0;
+                        if (voxel > 0.0 && reserve_raw(pf->filtered[slot], sizeof(double) * 3 * (size_t)n) == hipSuccess) {
                             const VoxelScratch vs{&pf->sc_bbox, &pf->sc_box, &pf->sc_keys, &pf->sc_vals, &pf->sc_tmp, 0};
                             const char *msg = "";
-                            int64_t nf = 0;
-                            if (voxel_filter_core(pf->stream, vs, pf->d_raw[slot], (int)n, voxel, (double *)pf->filtered[slot].p, n, &nf,
-                                                  true, &msg) == ICPMI_OK) {
-                                pf->filtered_n[slot] = nf;
-                                pf->filtered_voxel[slot] = voxel;
-                            } // (otherwise the push filters the raw points itself and reports what is wrong with them)
+                            filtered = voxel_filter_core(pf->stream, vs, pf->d_raw[slot], (int)n, voxel, (double *)pf->filtered[slot].p, n, &nf,
+                                                         true, &msg, true) == ICPMI_OK;
+                            // (otherwise the push filters the raw points itself and reports what is wrong with them)
+                        }
+                        // the points are on the device before the file is announced: the push needs no event
+                        // (a filter that gave up may have returned without waiting)
+                        ok = hipStreamSynchronize(pf->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+                        if (ok && filtered) {
+                            pf->filtered_n[slot] = nf;
+                            pf->filtered_voxel[slot] = voxel;
                         }
                     }
                 }
             }
             fclose(f);
         }
+        te = now();
+        pf->t_wait += tb - ta, pf->t_read += tc - tb, pf->t_upload += td - tc, pf->t_filter += te - td, pf->files += 1;
         lk.lock();
         if (ok) {
             pf->ready[slot] = path;

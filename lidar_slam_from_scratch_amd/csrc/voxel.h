@@ -79,11 +79,14 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(const double *__restric
                                                          const unsigned *__restrict__ order,
                                                          const unsigned *__restrict__ offsets,
                                                          const unsigned *__restrict__ counts, int runs,
-                                                         double *__restrict__ out)
+                                                         double *__restrict__ out,
+                                                         const unsigned *__restrict__ runs_dev = nullptr)
 {
+    // runs_dev: the number of voxels is still on the device (the prefetch worker queues the whole filter
+    // without a host round trip); `runs` is then the bound the grid was sized for (rows `out` holds)
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= runs) return; // wave-uniform
+    if (r >= runs || (runs_dev && (unsigned)r >= *runs_dev)) return; // wave-uniform
     const unsigned o = offsets[r], c = counts[r];
     double cx = 0.0, cy = 0.0, cz = 0.0;
     for (unsigned base = 0; base < c; base += 64) {
