@@ -226,6 +226,44 @@ def test_prefetched_frames_give_the_same_stream(tmp_path):
     ctx.close()
 
 
+def test_prefetched_files_the_worker_cannot_filter(tmp_path):
+    """The worker queues the filter of a prefetched file without looking at its outcome; the push of that file
+    does.  A scan whose grid cannot be keyed (a stray return three thousand kilometres away): the push then filters
+    the raw points itself and reports the same error as without the worker.  A file with trailing bytes (not a whole record) and a three-point file go
+    through like in the synchronous path.  The stream stays usable throughout."""
+    import run_sequence
+    run_sequence.write_synthetic_drive(str(tmp_path), 0, 4, beams=32, azimuths=900)
+    paths = [p for _, p in capi.discover_frames(str(tmp_path))]
+    cfg = capi.Context.make_config()
+    rec = np.fromfile(paths[2], dtype=np.float32).reshape(-1, 4)
+    bad = rec.copy(); bad[17, 1] = 3.0e6                      # 6e6 cells of 0.5 m on one axis: more than the 2^21 a key holds
+    bad_path = str(tmp_path / "900001.bin"); bad.tofile(bad_path)
+    odd_path = str(tmp_path / "900002.bin")
+    with open(odd_path, "wb") as f:
+        f.write(rec.tobytes() + b"\x01\x02\x03\x04\x05")       # file_utils.cpp:127: size / 16 records, the rest ignored
+    tiny_path = str(tmp_path / "900003.bin"); rec[:3].tofile(tiny_path)
+
+    def run(prefetch):
+        ctx = capi.Context(device=0)
+        out = []
+        for p in (paths[0], paths[1], bad_path, paths[2], odd_path, tiny_path, paths[3]):
+            if prefetch:
+                ctx.stream_prefetch_file(p)
+            try:
+                r, _, info = ctx.stream_push_file(p, 0.5, 1000, cfg)
+                out.append((info.status, info.n_filtered, r.num_iterations, tuple(r.transformation)))
+            except capi.IcpError as e:
+                out.append(("error", e.code, str(e)))
+        ctx.close()
+        return out
+
+    a, b = run(False), run(True)
+    assert a == b
+    assert a[2][0] == "error" and a[2][1] == capi.ERR_ARG and "voxel" in a[2][2]
+    assert a[3][0] == capi.STREAM_REGISTERED and a[4][0] == capi.STREAM_REGISTERED and a[4][1] == a[3][1]
+    assert a[5][0] == capi.STREAM_TOO_FEW_POINTS     # (and the frame after it registers against those three points: a == b covers it)
+
+
 def test_early_target_preparation_survives_foreign_calls(tmp_path, oracle):
     """A push queues the search structure and normals of the scan it has just filtered (the next push's target)
     behind its own result.  Calls in between that use the same buffers for other clouds -- a search, normals, a
