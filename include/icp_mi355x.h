@@ -171,10 +171,6 @@ int icpmi_voxel_downsample_device(icpmi_ctx *ctx, const double *d_points_xyz, in
  * NULL only *n_out is set.  A file that cannot be opened returns ICPMI_ERR_ARG (the
  * reference throws std::runtime_error). */
 int icpmi_load_cloud(const char *path, double *out_xyz, int64_t cap, int64_t *n_out);
-/* convertFile of tools/convert_to_ply.cpp:14-68: a KITTI ".bin" rewritten as the binary PLY (float x, y, z,
- * intensity) the reference's node loads.  Host-side, no context; *n_points (may be NULL) = records written. */
-int icpmi_bin_to_ply(const char *bin_path, const char *ply_path, int64_t *n_points);
-
 /* Replaces discover_frames + extract_timestamp (slam_viz/src/core/file_utils.cpp:203-247): the
  * entries of data_dir whose extension is ".ply" or ".bin" and whose name holds a run of digits in
  * front of that extension, sorted by that number (equal numbers by path).  Two-call pattern: with

@@ -399,34 +399,6 @@ public:
         }
         return out;
     }
-    // cells_to_occupancy_grid_msg (slam_node.cpp:279-297) without the ROS message around it
-    struct Raster {
-        double resolution = 0.0, origin_x = 0.0, origin_y = 0.0;
-        int width = 0, height = 0;
-        std::vector<int8_t> data; // row-major [y][x], 100 = occupied
-    };
-    Raster raster() const
-    {
-        Raster r;
-        const std::vector<GridCell> c = cells();
-        if (c.empty()) return r;                                  // :283
-        int minx = c[0].x, maxx = c[0].x, miny = c[0].y, maxy = c[0].y;
-        for (const GridCell &k : c) {                             // :285
-            minx = k.x < minx ? k.x : minx;
-            maxx = k.x > maxx ? k.x : maxx;
-            miny = k.y < miny ? k.y : miny;
-            maxy = k.y > maxy ? k.y : maxy;
-        }
-        minx -= 5, miny -= 5, maxx += 5, maxy += 5;               // :286
-        r.width = maxx - minx + 1;
-        r.height = maxy - miny + 1;
-        r.resolution = config_.resolution;
-        r.origin_x = minx * config_.resolution;                   // :291-292
-        r.origin_y = miny * config_.resolution;
-        r.data.assign(static_cast<std::size_t>(r.width) * static_cast<std::size_t>(r.height), 0);
-        for (const GridCell &k : c) r.data[static_cast<std::size_t>(k.y - miny) * r.width + (k.x - minx)] = 100; // :295
-        return r;
-    }
     const OccupancyGridConfig &config() const { return config_; }
 
 private:

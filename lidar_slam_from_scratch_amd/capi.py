@@ -22,7 +22,7 @@ EXPORTS = [
     "icpmi_nearest_batch", "icpmi_k_nearest", "icpmi_estimate_normals", "icpmi_solve_point_to_plane",
     "icpmi_transform_points", "icpmi_comm_unique_id", "icpmi_comm_init", "icpmi_comm_finalize",
     "icpmi_comm_init_callbacks", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
-    "icpmi_scan_context", "icpmi_scan_context_distances", "icpmi_load_cloud", "icpmi_bin_to_ply", "icpmi_load_cloud_device",
+    "icpmi_scan_context", "icpmi_scan_context_distances", "icpmi_load_cloud", "icpmi_load_cloud_device",
     "icpmi_upload_points_f32", "icpmi_discover_frames", "icpmi_estimate_normals_rows",
     "icpmi_stream_push", "icpmi_stream_push_host", "icpmi_stream_push_file", "icpmi_stream_prefetch_file", "icpmi_stream_reset",
     "icpmi_grid_config_default", "icpmi_occupancy_update", "icpmi_occupancy_update_device", "icpmi_occupancy_cells",
@@ -161,7 +161,6 @@ def load_library(path=None):
     L.icpmi_voxel_downsample.argtypes = [vp, dp, C.c_int64, C.c_double, dp, C.c_int64, i64p]
     L.icpmi_voxel_downsample_device.argtypes = [vp, vp, C.c_int64, C.c_double, vp, C.c_int64, i64p]
     L.icpmi_load_cloud.argtypes = [C.c_char_p, dp, C.c_int64, i64p]
-    L.icpmi_bin_to_ply.argtypes = [C.c_char_p, C.c_char_p, i64p]
     L.icpmi_load_cloud_device.argtypes = [vp, C.c_char_p, vp, C.c_int64, i64p]
     L.icpmi_upload_points_f32.argtypes = [vp, C.POINTER(C.c_float), C.c_int64, C.c_int32, vp]
     L.icpmi_discover_frames.argtypes = [C.c_char_p, i64p, C.c_int64, C.c_char_p, C.c_int64, i64p, i64p]
@@ -208,16 +207,6 @@ def load_cloud(path):
     if rc != OK:
         raise IcpError(rc, L.icpmi_last_error(None).decode())
     return out
-
-
-def bin_to_ply(bin_path, ply_path):
-    """convertFile (tools/convert_to_ply.cpp:14-68): KITTI .bin -> the binary PLY the reference's node loads; records written"""
-    L = load_library()
-    n = C.c_int64(0)
-    rc = L.icpmi_bin_to_ply(os.fsencode(bin_path), os.fsencode(ply_path), C.byref(n))
-    if rc != OK:
-        raise IcpError(rc, L.icpmi_last_error(None).decode())
-    return n.value
 
 
 def discover_frames(data_dir):

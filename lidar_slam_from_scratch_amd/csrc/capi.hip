@@ -1558,32 +1558,6 @@ int icpmi_voxel_downsample(icpmi_ctx *ctx, const double *points_xyz, int64_t n, 
     return ICPMI_OK;
 }
 
-// tools/convert_to_ply.cpp:14-68 (convertFile): a KITTI .bin rewritten as the binary PLY the reference's node
-// loads -- the same header (float x, y, z, intensity), the records copied as they are, a trailing partial
-// record dropped.  Host-side; the stream reads .bin directly, so nothing here needs it.
-int icpmi_bin_to_ply(const char *bin_path, const char *ply_path, int64_t *n_points)
-{
-    if (!bin_path || !ply_path) return fail(nullptr, ICPMI_ERR_NULL, "null argument");
-    if (n_points) *n_points = 0;
-    FILE *in = fopen(bin_path, "rb");
-    if (!in) return fail(nullptr, ICPMI_ERR_ARG, "Cannot open input file: %s", bin_path); // :17-20
-    struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } cin{in};
-    fseek(in, 0, SEEK_END);
-    const long size = ftell(in);
-    fseek(in, 0, SEEK_SET);
-    const size_t n = size > 0 ? (size_t)size / (4 * sizeof(float)) : 0; // :27
-    std::vector<float> rec(4 * n);
-    if (n > 0 && fread(rec.data(), 4 * sizeof(float), n, in) != n) return fail(nullptr, ICPMI_ERR_ARG, "short read of %s", bin_path);
-    FILE *out = fopen(ply_path, "wb");
-    if (!out) return fail(nullptr, ICPMI_ERR_ARG, "Cannot open output file: %s", ply_path); // :40-43
-    Closer cout{out};
-    fprintf(out, "ply\nformat binary_little_endian 1.0\nelement vertex %zu\nproperty float x\nproperty float y\n"
-                 "property float z\nproperty float intensity\nend_header\n", n); // :46-55
-    if (n > 0 && fwrite(rec.data(), 4 * sizeof(float), n, out) != n) return fail(nullptr, ICPMI_ERR_ARG, "short write of %s", ply_path);
-    if (n_points) *n_points = (int64_t)n;
-    return ICPMI_OK;
-}
-
 // ---- on-disk formats: host-side, no device work ------------------
 // KITTI .bin: x, y, z, intensity as float32, intensity dropped (file_utils.cpp:115-141).
 // PLY: header parse as file_utils.cpp:31-60 (every `property` line counts towards the vertex

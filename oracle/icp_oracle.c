@@ -15,6 +15,7 @@
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -476,6 +477,35 @@ void orc_estimate_normals(const double *points_xyz, int m, const orc_kdtree *t, 
         pthread_create(&th[w], NULL, normal_worker, &jobs[w]);
     }
     for (int w = 0; w < nthreads; ++w) pthread_join(th[w], NULL);
+}
+
+/* the same for rows [row0, row1) only (icp.hpp:30-64 is a loop over independent rows): out_xyz
+ * receives row1 - row0 rows.  What a test of a row slice needs without paying for the whole cloud. */
+void orc_estimate_normals_rows(const double *points_xyz, int m, const orc_kdtree *t, int k, int row0,
+                               int row1, double *out_xyz, int nthreads)
+{
+    if (row0 < 0) row0 = 0;
+    if (row1 > m) row1 = m;
+    const int rows = row1 - row0;
+    if (rows <= 0) return;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > ORC_MAX_THREADS) nthreads = ORC_MAX_THREADS;
+    if (k < 1) k = 1;
+    if (rows < 4 * nthreads) nthreads = 1;
+    pthread_t th[ORC_MAX_THREADS];
+    normal_job jobs[ORC_MAX_THREADS];
+    for (int w = 0; w < nthreads; ++w) {
+        jobs[w].points = points_xyz;
+        jobs[w].t = t;
+        jobs[w].k = k;
+        jobs[w].begin = row0 + (int)((long long)rows * w / nthreads);
+        jobs[w].end = row0 + (int)((long long)rows * (w + 1) / nthreads);
+        jobs[w].normals = out_xyz - 3 * (ptrdiff_t)row0; /* the worker writes row i at normals + 3 i */
+        if (nthreads == 1) normal_worker(&jobs[w]);
+        else pthread_create(&th[w], NULL, normal_worker, &jobs[w]);
+    }
+    if (nthreads > 1)
+        for (int w = 0; w < nthreads; ++w) pthread_join(th[w], NULL);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -48,6 +48,9 @@ int orc_k_nearest_brute(const double *targets_xyz, int m, const double query[3],
 /* icp.hpp:23-67 (estimate_normals). */
 void orc_estimate_normals(const double *points_xyz, int m, const orc_kdtree *t, int k,
                           double *normals_xyz, int nthreads);
+/* rows [row0, row1) only; out_xyz receives row1 - row0 rows */
+void orc_estimate_normals_rows(const double *points_xyz, int m, const orc_kdtree *t, int k, int row0,
+                               int row1, double *out_xyz, int nthreads);
 
 /* icp.hpp:89-144 (solve_point_to_plane) -> row-major 4x4. */
 void orc_solve_point_to_plane(const double *source_xyz, const double *target_xyz,

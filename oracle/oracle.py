@@ -58,6 +58,7 @@ def lib():
         L.orc_k_nearest_brute.restype = C.c_int
         L.orc_k_nearest_brute.argtypes = [dp, C.c_int, dp, C.c_int, ip]
         L.orc_estimate_normals.argtypes = [dp, C.c_int, C.c_void_p, C.c_int, dp, C.c_int]
+        L.orc_estimate_normals_rows.argtypes = [dp, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, dp, C.c_int]
         L.orc_solve_point_to_plane.argtypes = [dp, dp, dp, C.c_int, dp]
         L.orc_normal_equations.argtypes = [dp, dp, dp, C.c_int, dp]
         L.orc_solve_from_sums.argtypes = [dp, dp]
@@ -137,6 +138,16 @@ def estimate_normals(points, tree=None, k=20, nthreads=1):
     out = np.empty_like(p)
     lib().orc_estimate_normals(pp, p.shape[0], tree._h, k, out.ctypes.data_as(C.POINTER(C.c_double)),
                                nthreads)
+    return out
+
+
+def estimate_normals_rows(points, row0, row1, tree=None, k=20, nthreads=1):
+    """icp.hpp:23-67 for rows [row0, row1) only -> (row1 - row0) x 3"""
+    p, pp = _d(points)
+    tree = tree or KDTree(p)
+    out = np.empty((max(0, row1 - row0), 3))
+    lib().orc_estimate_normals_rows(pp, p.shape[0], tree._h, k, int(row0), int(row1),
+                                    out.ctypes.data_as(C.POINTER(C.c_double)), nthreads)
     return out
 
 

@@ -26,18 +26,36 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def write_synthetic_drive(out_dir, first, last, beams=64, azimuths=1800):
+def _write_frame(job):
+    out_dir, f, beams, azimuths = job
+    from lidar_slam_from_scratch_amd import synth
+    pts = synth.lidar_frame(f, voxel=0, beams=beams, azimuths=azimuths, **synth.DRIVE_200)
+    rec = np.zeros((pts.shape[0], 4), dtype=np.float32)
+    rec[:, :3] = pts
+    rec.tofile(os.path.join(out_dir, "%06d.bin" % f))
+    return f
+
+
+def write_synthetic_drive(out_dir, first, last, beams=64, azimuths=1800, workers=1):
     """SURVEY 8d C5 stand-in: the C2 scene driven through (synth.DRIVE_200: 0.6 m per frame); raw scans as
-    KITTI .bin (x, y, z, intensity float32) named like KITTI's velodyne files.  Returns ground truth."""
+    KITTI .bin (x, y, z, intensity float32) named like KITTI's velodyne files.  Returns ground truth.
+    workers > 1: the frames are ray-cast by that many child processes of this script (`--write-frames`;
+    numpy only, started fresh and never forked: the caller may hold a GPU context)."""
     from lidar_slam_from_scratch_amd import synth
     os.makedirs(out_dir, exist_ok=True)
-    truth = []
-    for f in range(first, last):
-        pts = synth.lidar_frame(f, voxel=0, beams=beams, azimuths=azimuths, **synth.DRIVE_200)
-        rec = np.zeros((pts.shape[0], 4), dtype=np.float32)
-        rec[:, :3] = pts
-        rec.tofile(os.path.join(out_dir, "%06d.bin" % f))
-        truth.append(synth.lidar_pose(f, **synth.DRIVE_200))
+    jobs = [(out_dir, f, beams, azimuths) for f in range(first, last)]
+    workers = max(1, min(workers, len(jobs)))
+    if workers > 1:
+        import subprocess
+        kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--write-frames", out_dir,
+                                  "--frames", "%d:%d" % (first + w, last), "--frame-step", str(workers),
+                                  "--beams", str(beams), "--azimuths", str(azimuths)]) for w in range(workers)]
+        if any(k.wait() != 0 for k in kids):
+            raise RuntimeError("a frame writer failed")
+    else:
+        for j in jobs:
+            _write_frame(j)
+    truth = [synth.lidar_pose(f, **synth.DRIVE_200) for f in range(first, last)]
     np.save(os.path.join(out_dir, "truth_poses.npy"), np.array(truth))
     return truth
 
@@ -61,7 +79,14 @@ def main():
                     help="per frame also the map side of process_frame (slam_node.cpp:147-153): world points of the resident scan "
                          "and the occupancy-grid insert, on the device; with --oracle the cell set is compared with the oracle's")
     ap.add_argument("--world-out", action="store_true", help="with --map: copy every frame's world points to the host (what :155 publishes)")
+    ap.add_argument("--write-frames", metavar="DIR", help="(internal) only write the synthetic frames a:b:step there and exit")
+    ap.add_argument("--frame-step", type=int, default=1)
     args = ap.parse_args()
+    if args.write_frames:
+        a, b = args.frames.split(":")
+        for f in range(int(a), int(b), args.frame_step):
+            _write_frame((args.write_frames, f, args.beams, args.azimuths))
+        return 0
     lo, hi = 0, None
     if args.frames:
         a, b = args.frames.split(":")

@@ -52,14 +52,6 @@ int main(int argc, char **argv)
             out.push_back(c.x);
             out.push_back(c.y);
         }
-        const im::OccupancyGrid::Raster r = grid.raster();               // slam_node.cpp:279-297
-        std::size_t occupied = 0;
-        for (int8_t v : r.data) occupied += v == 100;
-        out.push_back(r.width);
-        out.push_back(r.height);
-        out.push_back(r.origin_x);
-        out.push_back(r.origin_y);
-        out.push_back(static_cast<double>(occupied));
         std::ofstream f(argv[1], std::ios::binary);
         f.write(reinterpret_cast<const char *>(out.data()), static_cast<std::streamsize>(out.size() * sizeof(double)));
         return 0;

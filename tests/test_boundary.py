@@ -128,7 +128,7 @@ def test_cpp_adapter_compiles_against_a_minimal_cloud_type(tmp_path):
         "       auto s2 = st.push_file(\"x.bin\", 0.5, 1000, c); icp_mi355x::OccupancyGridConfig g; std::size_t nc = 0;\n"
         "       auto w = st.map_update(icp_mi355x::Transformation(), &g, &nc); auto cur = st.current_scan(); st.reset();\n"
         "       (void)s1; (void)s2; (void)w; (void)cur; } catch (const std::exception&) { }\n"
-        " try { icp_mi355x::OccupancyGrid og; og.update(a, {0.0, 0.0, 0.0}); auto r = og.raster(); og.clear(); (void)r; }\n"
+        " try { icp_mi355x::OccupancyGrid og; og.update(a, {0.0, 0.0, 0.0}); auto r = og.cells(); og.clear(); (void)r; }\n"
         " catch (const std::exception&) { }\n"
         " try { icp_mi355x::LoopClosureDetector det; det.addFrame(a, 0); auto f = det.detect();\n"
         "       auto sc = icp_mi355x::ScanContext::compute(a); (void)sc.distance(sc); (void)f; } catch (const std::exception&) { }\n"
@@ -178,27 +178,6 @@ def test_load_cloud_kitti_bin_and_ply(tmp_path, lib):
     empty = tmp_path / "e.bin"
     empty.write_bytes(b"")
     assert capi.load_cloud(str(empty)).shape == (0, 3)
-
-
-def test_bin_to_ply_is_the_converter_tool(tmp_path, lib):
-    """tools/convert_to_ply.cpp:14-68 (convertFile): the PLY written from a KITTI .bin carries the header the tool
-    writes and the records as they are (a trailing partial record dropped), and loads back to the .bin's points."""
-    rng = np.random.default_rng(9)
-    rec = rng.normal(0, 30, (777, 4)).astype(np.float32)
-    kitti = tmp_path / "000007.bin"
-    kitti.write_bytes(rec.tobytes() + b"\x01\x02\x03\x04\x05")       # 5 stray bytes: not a whole record
-    ply = tmp_path / "000007.ply"
-    assert capi.bin_to_ply(str(kitti), str(ply)) == 777
-    raw = ply.read_bytes()
-    header = (b"ply\nformat binary_little_endian 1.0\nelement vertex 777\nproperty float x\nproperty float y\n"
-              b"property float z\nproperty float intensity\nend_header\n")                    # convert_to_ply.cpp:46-55
-    assert raw.startswith(header) and raw[len(header):] == rec.tobytes()
-    assert (capi.load_cloud(str(ply)) == capi.load_cloud(str(kitti))).all()
-    empty = tmp_path / "e.bin"
-    empty.write_bytes(b"")
-    assert capi.bin_to_ply(str(empty), str(tmp_path / "e.ply")) == 0 and capi.load_cloud(str(tmp_path / "e.ply")).shape == (0, 3)
-    with pytest.raises(capi.IcpError):
-        capi.bin_to_ply(str(tmp_path / "missing.bin"), str(tmp_path / "m.ply"))
 
 
 def test_hip_runtime_guard_parses_maps():

@@ -1,5 +1,6 @@
 """The N > 1 path on CPU: world_size-2 gloo.  Checks the host-side sharding logic and the
-one exchange of the path (all-reduce of the 29-double normal-equation vector): sharded
+one exchange of the path (all-reduce of the 30-double normal-equation vector: 28 sums, the count and the
+number of ranks whose loop has ended): sharded
 sums -> identical bits on every rank -> same pose as the unsharded run.  The per-shard
 arithmetic is done by the oracle here (no GPU in this container); the same sharded path
 through the HIP library is exercised by tests/test_gpu_dist.py on the GPU box."""
@@ -40,7 +41,7 @@ def _worker(rank, world, port, out_dir):
     hist, conv = [], False
     for _ in range(50):  # icp.hpp:181-232 with the sums exchanged
         idx, _d = tree.nearest_batch(cur)
-        local = np.zeros(29)
+        local = np.zeros(30)  # [29]: ranks whose loop has ended (none while this loop runs)
         local[:28] = orc.normal_equations(cur, tgt[idx], normals[idx])
         local[28] = cur.shape[0]
         sums = icpdist.reduce_normal_equations(local, dist)

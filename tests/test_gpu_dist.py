@@ -1,5 +1,5 @@
 """The sharded path THROUGH THE HIP LIBRARY with two ranks on one GPU: k_finish ->
-all-reduce(29 doubles) -> k_step, and row-sliced normals + all-gather, with the exchanges
+all-reduce(30 doubles) -> k_step, and row-sliced normals + all-gather, with the exchanges
 carried by gloo host callbacks (RCCL refuses two ranks on one device; the 8-GPU RCCL run
 is the driver's).  Result must equal the single-rank GPU run and the oracle."""
 import os
@@ -118,7 +118,7 @@ def test_sharded_align_on_one_gpu(tmp_path, oracle, gpu_ctx, world, npts):
 @pytest.mark.parametrize("search", [0, 3], ids=["auto", "mfma_pruned"])
 def test_rccl_single_rank_communicator(oracle, search):
     """The RCCL plumbing on real hardware (dlopen, unique id, ncclCommInitRank, in-place
-    all-gather of the normals, 29-double all-reduce on the library's stream) with a 1-rank
+    all-gather of the normals, 30-double all-reduce on the library's stream) with a 1-rank
     communicator: the sharded code path must reproduce the plain single-GPU result."""
     from lidar_slam_from_scratch_amd import capi, synth
     src, tgt, _ = synth.c3_uniform(12000, seed=41, perm_seed=42)
@@ -147,7 +147,7 @@ def test_bench_starts_its_own_ranks():
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-gloo", "--steps", "4",
-                          "--warmup", "1", "--points", "20000", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                          "--warmup", "1", "--points", "20000", "--no-cpu-baseline", "--repeats", "3"], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -155,3 +155,58 @@ def test_bench_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
     assert "REHEARSAL" in d["config"]["parallelism"] and d["roofline"]["frac"] > 0
+
+
+def test_c4_eight_ranks_rehearsal(oracle):
+    """BASELINE.json configs[3] as a whole: synthetic 1M -> 1M, the source cut into 8 shards of 125k rows,
+    the normals of the 1M target computed in 8 row slices and all-gathered, 30 doubles all-reduced per
+    iteration -- all eight ranks through the HIP library on this box's ONE GPU.  The ranks are eight
+    threads of this process (the GPU boxes admit six processes on a card, so eight gloo processes
+    cannot share it; tests above run the same callbacks across processes with 2 and 3 ranks), one
+    context and stream each, the exchanges through icpdist.LocalGroup.  Asserted: every rank returns
+    identical bits; history and pose equal the unsharded single-GPU 1M -> 1M run's to 1e-12 and the
+    oracle's to 1e-9; the all-gathered normals equal estimate_normals of the whole target bit for bit."""
+    from lidar_slam_from_scratch_amd import capi, dist as icpdist, synth
+    world, iters = 8, 3
+    src, tgt, _ = synth.c4_uniform()
+    assert src.shape[0] == tgt.shape[0] == 1_000_000
+    cfg = capi.Context.make_config(iters, 0.0, 0.0)
+    group = icpdist.LocalGroup(world)
+
+    def rank_body(rank):
+        lo, hi = icpdist.shard_bounds(src.shape[0], world, rank)
+        assert hi - lo == 125_000
+        ctx = capi.Context(device=0)
+        group.attach(ctx, rank)
+        res, hist = ctx.align(src[lo:hi], tgt, cfg)
+        out = (np.array(res.transformation[:]).reshape(4, 4), hist, res.num_iterations, bool(res.converged), res.loop_iterations)
+        ctx.comm_finalize()
+        ctx.close()
+        return out
+
+    r = group.run(rank_body)
+    for k in range(1, world):
+        assert (r[k][0] == r[0][0]).all() and (r[k][1] == r[0][1]).all() and r[k][2:] == r[0][2:]
+    T, hist, n_it, conv, loops = r[0]
+    assert (n_it, conv, loops) == (iters, False, iters) and hist.shape[0] == iters + 1
+    assert group.allreduces == iters + 1                      # one exchange per loop pass + the post-loop pass
+    # the normals every rank ended up with: 8 slices of 125k rows, gathered
+    per = (tgt.shape[0] + world - 1) // world
+    gathered = group.gathered.reshape(-1, 3)[:tgt.shape[0]]
+    assert group.gathered.shape[0] == 3 * per * world
+    nth = os.cpu_count() or 1
+    want_nrm = oracle.estimate_normals(tgt, None, 20, nthreads=nth)
+    assert (gathered == want_nrm).all()
+    # the unsharded job on one context (2.9 GB of coarse minima), and the oracle loop
+    one = capi.Context(device=0)
+    assert (one.estimate_normals(tgt, 20) == want_nrm).all()
+    res1, hist1 = one.align(src, tgt, cfg)
+    one.close()
+    assert res1.num_iterations == n_it
+    np.testing.assert_allclose(hist, hist1, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(T, np.array(res1.transformation[:]).reshape(4, 4), rtol=0, atol=1e-12)
+    ref = oracle.icp_point_to_plane(src, tgt, iters, 0.0, 0.0, faithful=False, nthreads=nth)
+    assert ref.num_iterations == n_it and ref.converged == conv
+    np.testing.assert_allclose(hist, ref.error_history, rtol=0, atol=1e-9)
+    dt, dr = synth.pose_delta(T, ref.transformation)
+    assert dt <= 1e-9 and dr <= 1e-9

@@ -126,7 +126,7 @@ def test_stream_map_update_is_the_map_side_of_process_frame(tmp_path, oracle):
 def test_cpp_stream_mirror(tmp_path):
     """include/icp_mi355x.hpp's OdometryStream + OccupancyGrid from a plain C++17 program
     (tests/cpp/stream_demo.cpp) against the same loop driven from Python through the same C ABI:
-    statuses, iteration counts, poses, world-point checksums, the cell set and its raster must agree exactly."""
+    statuses, iteration counts, poses, world-point checksums, and the cell set must agree exactly."""
     import subprocess
     import run_sequence
     from lidar_slam_from_scratch_amd import build
@@ -162,8 +162,4 @@ def test_cpp_stream_mirror(tmp_path):
     cells = ctx.occupancy_cells()
     n = int(o[p]); p += 1
     assert n == cells.shape[0] and (o[p:p + 2 * n].reshape(n, 2) == cells).all()
-    p += 2 * n
-    w, h, ox, oy, occ = o[p:p + 5]
-    assert int(w) == cells[:, 0].max() - cells[:, 0].min() + 11 and int(h) == cells[:, 1].max() - cells[:, 1].min() + 11
-    assert ox == (cells[:, 0].min() - 5) * 0.2 and oy == (cells[:, 1].min() - 5) * 0.2 and int(occ) == n
     ctx.close()
