@@ -30,6 +30,7 @@
 #include "../../include/icp_mi355x.h"
 #include "kernels.h"
 #include "nn_mfma.h"
+#include "icp_small.h"
 #include "voxel.h"
 #include "scan_context.h"
 #include "occupancy.h"
@@ -162,6 +163,7 @@ struct icpmi_ctx {
 
     DevBuf cur, nrm, idx, part_d2, part_idx, partials, history, stage_a, stage_b, stage_c, d2out;
     DevBuf knn_idx, slotmin, fb_list;         // k-NN lists, slot minima, rows for the exact fallback
+    DevBuf nrm_sorted;                        // small-cloud kernel: the target normals in Morton order (SoA, stride nn_ms)
     DevBuf vox_keys, vox_vals, vox_out;             // voxel filter: 64-bit keys (in/out/unique), values + run data, result
     DevBuf stream_prev, stream_cur, f32_stage;      // odometry stream: previous / current filtered scan; float32 upload staging
     int64_t stream_prev_n = -1;                     // rows of stream_prev (-1: no frame yet)
@@ -375,6 +377,36 @@ int finish_transform_blocks(int n)
         return 32;
     }();
     return std::max(1, std::min(cap, (n + kFinishThreads - 1) / kFinishThreads));
+}
+
+// Small clouds (the reference's real callers: filtered scans of 5-20k points): search, residuals and
+// pose update of the rows in ONE kernel per iteration (icp_small.h) when the target is at most
+// kSmallMaxSplits splits and the source at most this many rows (beyond, the general path's 512-query
+// units amortise the operand reads better).  ICPMI_SMALL=0 switches the path off (A/B runs, parity
+// test); ICPMI_SMALL_MAX_QUERIES moves the row limit.
+bool small_enabled()
+{
+    static const bool v = [] {
+        const char *e = getenv("ICPMI_SMALL");
+        return !(e && e[0] == '0' && e[1] == '\0');
+    }();
+    return v;
+}
+int small_max_queries()
+{
+    static const int v = [] {
+        if (const char *e = getenv("ICPMI_SMALL_MAX_QUERIES")) {
+            const long x = strtol(e, nullptr, 10);
+            if (x >= 0 && x <= 100000000) return (int)x;
+        }
+        return 32768;
+    }();
+    return v;
+}
+// (by the target alone: whether its Morton-ordered normals are worth keeping)
+bool small_target(const icpmi_ctx *ctx)
+{
+    return small_enabled() && ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && !ctx->nn_pruned && ctx->nn_splits <= kSmallMaxSplits;
 }
 
 // Choose and prepare the search engine for a target cloud (once per call: the target does
@@ -768,6 +800,19 @@ int exchange_allgather(icpmi_ctx *ctx, double *d_buf, size_t per)
     return ICPMI_OK;
 }
 
+// The target normals (ctx->nrm, by point) once more in the target's Morton order, for the small-cloud
+// kernel: its slot scans then read a candidate's normal next to its coordinates.
+int sort_normals(icpmi_ctx *ctx, int m)
+{
+    if (!small_target(ctx)) return ICPMI_OK;
+    int rc;
+    if ((rc = reserve(ctx, ctx->nrm_sorted, sizeof(double) * 3 * (size_t)ctx->nn_ms))) return rc;
+    hipLaunchKernelGGL(k_gather_points, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (const double *)ctx->nrm.p,
+                       (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m, m, ctx->nn_ms, (double *)ctx->nrm_sorted.p);
+    HIP_TRY(ctx, hipGetLastError());
+    return ICPMI_OK;
+}
+
 // ---- the ICP call, device pointers -----------------------------------------------------
 // Search structure + normals of a target for a single-GPU registration (icp.hpp:169-171), queued on the
 // context's stream; remembered, so that an align against the same device pointer and size with the
@@ -780,6 +825,7 @@ int prepare_target(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     const bool sorted_rows = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && ctx->nn_pruned && ctx->opt.normal_k <= 32 &&
                              m >= mfma_min_targets();
     if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, 0, m, (double *)ctx->nrm.p, sorted_rows, true))) return rc;
+    if ((rc = sort_normals(ctx, m))) return rc;
     ctx->prep_tgt = d_tgt;
     ctx->prep_m = m;
     ctx->prep_engine = engine_for(ctx, m, n_hint);
@@ -833,7 +879,9 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     if (!prepared && (rc = prepare_nn(ctx, d_tgt, m, n))) return rc;
     // with the MFMA engine the resolve kernel also forms the normal-equation partial sums
     const bool fused = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16;
-    const int rblocks = fused ? resolve_blocks(n) : reduce_blocks(ctx, n);
+    // small clouds: one kernel per iteration for the rows' work (icp_small.h), then k_finish_step
+    const bool small = !sharded_run && n > 0 && n <= small_max_queries() && small_target(ctx);
+    const int rblocks = small ? (n + kSmallQ - 1) / kSmallQ : (fused ? resolve_blocks(n) : reduce_blocks(ctx, n));
     if ((rc = reserve(ctx, ctx->partials, sizeof(double) * kSumsStride * (size_t)rblocks))) return rc;
     double *partials = (double *)ctx->partials.p;
 
@@ -860,6 +908,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                                         hipMemcpyDeviceToDevice, s));
     } else if (!prepared) {
         if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, 0, m, nrm, sorted_rows, true))) return rc;
+        if ((rc = sort_normals(ctx, m))) return rc;
     }
     ctx->prep_valid = false; // (the stream path prepares the next target below; nothing else relies on it)
 
@@ -902,7 +951,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     }
 
     // current_source = source * R0^T + t0^T (icp.hpp:174-176)
-    if (n > 0) { // (an empty shard of a sharded run launches nothing over its rows)
+    if (n > 0 && !small) { // (an empty shard of a sharded run launches nothing over its rows; the small-cloud kernel moves them itself)
         StageTimer t(ctx, ST_TRANSFORM);
         if (pruned)
             hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, d_src, src_perm, cur, n,
@@ -913,8 +962,38 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                                cur, n, st, 1, 0);
     }
 
+    unsigned long long *small_clocks = nullptr;
+#ifdef ICPMI_SMALL_CLOCKS /* diagnostic build: the stamps of the last pass land in the (idle) slot-minimum buffer */
+    if (small) {
+        if ((rc = reserve(ctx, ctx->slotmin, sizeof(unsigned long long) * 2 * kSmallStamps * (size_t)rblocks))) return rc;
+        small_clocks = (unsigned long long *)ctx->slotmin.p;
+    }
+#endif
+    bool small_first = true; // the small-cloud kernel's first pass applies the initial transform to the caller's rows
     auto iteration = [&](int final_pass, int *progress, int ticket) -> int {
         int r2;
+        if (small) {
+            {
+                Range range("icpmi:nn_search");
+                StageTimer t(ctx, ST_NN);
+#define ICPMI_SMALL_ARGS                                                                                                        \
+    small_first ? d_src : (const double *)cur, cur, n, (const IcpState *)st, small_first ? 1 : 0, (const uint4 *)ctx->bpack.p,    \
+        frames, splits, (const double *)ctx->tgt_sorted.p, (const double *)ctx->nrm_sorted.p,                                       \
+        (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m, m, ctx->nn_ms, d_tgt, (const double *)nrm, partials,                    \
+        (unsigned long long *)((char *)ctx->nn_misc.p + 128), small_clocks
+                hipLaunchKernelGGL(k_icp_small, dim3(rblocks), dim3(kSmallThreads), 0, s, ICPMI_SMALL_ARGS);
+#undef ICPMI_SMALL_ARGS
+                small_first = false;
+                ctx->prof.nn_pairs += (double)n * (double)m;
+                ctx->prof.small_launches += 1;
+                ctx->prof.nn_coarse_blocks += (int64_t)((n + kCoarseQueries - 1) / kCoarseQueries) * splits; // the units the general path would run
+            }
+            Range range("icpmi:reduce_solve");
+            StageTimer t(ctx, ST_REDUCE);
+            hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n, st, hist, final_pass, progress, ticket);
+            HIP_TRY(ctx, hipGetLastError());
+            return ICPMI_OK;
+        }
         const bool fuse_step = sharded && !pruned && n > 0 && !final_pass;
         const bool fuse_finish = !sharded && !pruned && n > 0 && !final_pass && fuse_finish_enabled();
         if (n > 0 && fused) {
@@ -1312,7 +1391,7 @@ void icpmi_destroy(icpmi_ctx *ctx)
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
     for (DevBuf *b : {&ctx->cur, &ctx->nrm, &ctx->idx, &ctx->part_d2, &ctx->part_idx, &ctx->partials,
                       &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out, &ctx->src_sort, &ctx->blk_lists, &ctx->work,
-                      &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin,
+                      &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin, &ctx->nrm_sorted,
                       &ctx->fb_list, &ctx->sort_keys, &ctx->sort_tmp, &ctx->tgt_sorted, &ctx->frames, &ctx->vox_keys,
                       &ctx->vox_vals, &ctx->vox_out, &ctx->stream_prev, &ctx->stream_cur, &ctx->f32_stage, &ctx->grid_set,
                       &ctx->grid_in, &ctx->grid_out, &ctx->grid_cnt, &ctx->world})
@@ -2365,7 +2444,7 @@ int icpmi_get_profile(icpmi_ctx *ctx, icpmi_profile *out)
     return ICPMI_OK;
 }
 
-#ifdef ICPMI_COARSE_CLOCKS
+#if defined(ICPMI_COARSE_CLOCKS) || defined(ICPMI_SMALL_CLOCKS)
 // diagnostic build only: the stamps of the last all-pairs 1-NN pass (4 words per workgroup:
 // s_memtime, s_memrealtime at its start and at its end)
 int icpmi_debug_coarse_clocks(icpmi_ctx *ctx, unsigned long long *out, int64_t words)

@@ -62,12 +62,7 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const double *__restrict__ p
     vals[i] = (unsigned)i;
 }
 
-// lane `l` (wave-uniform) of a double, through the scalar unit
-__device__ __forceinline__ double readlane_f64(double v, int l)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
+// (readlane_f64: lane `l` (wave-uniform) of a double, through the scalar unit -- icp_small.h)
 
 // One WAVE per voxel.  The centroid must add the voxel's points in input order (the sort is
 // stable) like file_utils.cpp:188-190, so the three sums are serial chains -- but the loads

@@ -922,3 +922,57 @@ print(json.dumps(out))
         legs[knob] = json.loads(r.stdout.strip().splitlines()[-1])
     assert legs["0"] == legs["1"]
     assert all(v["iters"] >= 2 for v in legs["1"].values())
+
+
+def test_small_cloud_kernel_gives_the_general_path_bits():
+    """icp_small.h: for targets of at most 16 splits the rows' work of an iteration (pose update, coarse
+    pass, resolve, normal-equation terms) is ONE kernel whose intermediate never leaves LDS.  Against the
+    general path (ICPMI_SMALL=0: k_nn_coarse + k_nn_resolve4 + k_finish_step_transform) the partial rows
+    are formed from the same correspondences in the same order, so pose, history and counts must agree
+    BIT FOR BIT: room corner at 300 / 5,000 points (1 / 3 splits), uniform clouds of 12k (6 splits) and
+    20k -> 30k (15 splits), a LiDAR-like frame pair, a cloud full of exact ties (integer grid with
+    duplicates), a source with a NaN row, and an initial transform."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from lidar_slam_from_scratch_amd import capi, synth
+ctx = capi.Context(device=0, profile=1)
+cases = {}
+for n in (300, 5000):
+    cases["corner%%d" %% n] = synth.c1_room_corner(n)[:2] + (None,)
+cases["uniform12k"] = synth.c3_uniform(12000, seed=51, perm_seed=52)[:2] + (None,)
+s, t, _ = synth.c3_uniform(30000, seed=61, perm_seed=62)
+cases["uniform20k_30k"] = (s[:20000], t, None)
+cases["lidar"] = (synth.lidar_frame(1), synth.lidar_frame(0), None)
+rng = np.random.default_rng(5)
+grid = rng.integers(-12, 12, (9000, 3)).astype(np.float64)
+cases["ties"] = (grid[:4000] + 0.25, grid, None)
+s, t, _ = synth.c1_room_corner(4000)
+s = s.copy(); s[17] = np.nan
+cases["nan_row"] = (s, t, None)
+T0 = np.eye(4); T0[:3, 3] = (0.05, -0.02, 0.01)
+cases["initial"] = synth.c1_room_corner(3000)[:2] + (T0,)
+out = {}
+for name, (src, tgt, init) in cases.items():
+    cfg = capi.Context.make_config(max_iterations=12, tolerance=1e-7, initial_transform=init)
+    res, hist = ctx.align(src, tgt, cfg)
+    out[name] = {"T": [float.hex(v) for v in res.transformation[:]], "hist": [float.hex(v) for v in hist],
+                 "iters": res.num_iterations, "converged": int(res.converged)}
+out["small_launches"] = ctx.get_profile()["small_launches"]
+print(json.dumps(out))
+''' % root
+    legs = {}
+    for knob in ("0", "1"):
+        env = dict(os.environ, ICPMI_SMALL=knob)
+        r = subprocess.run([sys.executable, "-c", child], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        legs[knob] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert legs["0"].pop("small_launches") == 0 and legs["1"].pop("small_launches") > 20
+    assert legs["0"] == legs["1"]
+    assert all(v["iters"] >= 1 for v in legs["1"].values())
