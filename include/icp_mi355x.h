@@ -22,7 +22,12 @@
  *     non-blocking HIP stream that is NOT ordered against any stream of the caller
  *     (torch's current stream included).  Device inputs must be complete and visible
  *     before the call (synchronise the producing stream, or wait on its event, first);
- *     device outputs are complete when the call returns.
+ *     device outputs are complete when the call returns.  One exception in what "returns" means:
+ *     icpmi_stream_push* hand back their RESULTS complete, but may leave kernels of the library's own
+ *     queued on that stream -- the search structure and normals of the scan just filtered, the next
+ *     push's target -- so that the device builds them while the caller digests the result.  They touch
+ *     only the context's workspace; every later call on the context is ordered behind them, and a
+ *     fault in them is reported by that next call as a failure of the preparation step.
  *   - there is no CPU fallback: with no usable HIP device icpmi_create fails.
  */
 #ifndef ICP_MI355X_H
@@ -121,6 +126,20 @@ int icpmi_align_device(icpmi_ctx *ctx, const double *d_source_xyz, int64_t n_src
                        const double *d_target_xyz, int64_t n_tgt, const icpmi_config *cfg,
                        icpmi_result *result, double *error_history, int32_t history_cap);
 
+/* Several independent registrations at once: the up-to-three ICP verifications of one
+ * LoopClosureDetector::detect() (loop_closure.hpp:94-123), each a slam::icp_point_to_plane call of its own in
+ * the reference.  Problem k runs on a stream and workspace of its own (helper contexts the library keeps
+ * inside `ctx`, created on first use with ctx's options), driven by a host thread of its own, so the
+ * registrations share the GPU: a filtered scan fills the chip for a part of each iteration only.
+ * Every result is bit-identical to the same icpmi_align call made alone.  Host pointers; cfgs, results,
+ * status: `count` entries; error_history: `count` rows of history_stride doubles (>= cfgs[k].max_iterations + 1).
+ * status[k] is problem k's return code; the call returns ICPMI_OK if all are, else the first that is not
+ * (its text in icpmi_last_error(ctx)).  1 <= count <= ICPMI_MAX_BATCH; not for a context with a communicator. */
+#define ICPMI_MAX_BATCH 8
+int icpmi_align_batch(icpmi_ctx *ctx, int32_t count, const double *const *sources_xyz, const int64_t *n_src,
+                      const double *const *targets_xyz, const int64_t *n_tgt, const icpmi_config *cfgs,
+                      icpmi_result *results, double *error_history, int32_t history_stride, int32_t *status);
+
 /* Replaces KDTree(points) + KDTree::nearest_batch (kdtree.hpp:20-26,43-59): for each
  * query the index of, and squared distance to, its nearest target.  Host pointers;
  * dist_sq may be NULL. */
@@ -157,7 +176,8 @@ int icpmi_transform_points(icpmi_ctx *ctx, const double transform[16], const dou
  * occupied voxel, key = floor(coord / voxel_size), points summed in input order.  Voxels come
  * out sorted by key (the reference's order is std::unordered_map iteration order, i.e.
  * implementation-defined).  voxel_size <= 0 copies the input (file_utils.cpp:152).  out_cap
- * is in rows; n rows always suffice.  The grid may span at most 2^21 cells per axis. */
+ * is in rows; n rows always suffice.  The grid may span at most 2^21 cells per axis; a point with a NaN or
+ * infinite coordinate (undefined behaviour in the reference: the cast of floor(NaN)) is ICPMI_ERR_ARG. */
 int icpmi_voxel_downsample(icpmi_ctx *ctx, const double *points_xyz, int64_t n, double voxel_size,
                            double *out_xyz, int64_t out_cap, int64_t *n_out);
 /* Same on device pointers (the result can feed icpmi_align_device without leaving HBM). */

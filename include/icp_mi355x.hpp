@@ -222,6 +222,41 @@ inline ICPResult icp_point_to_plane(Context &ctx, const double *source_xyz, std:
     return out;
 }
 
+// Several independent registrations of one source at once (icpmi_align_batch): what the verifications of one
+// LoopClosureDetector::detect() are (loop_closure.hpp:94-123).  Each result is that of icp_point_to_plane alone.
+inline std::vector<ICPResult> icp_point_to_plane_batch(Context &ctx, const PointCloud &source,
+                                                       const std::vector<const PointCloud *> &targets, const ICPConfig &config)
+{
+    const std::size_t k = targets.size();
+    std::vector<ICPResult> out(k);
+    if (k == 0) return out;
+    std::vector<const double *> sp(k, source.data()), tp(k);
+    std::vector<int64_t> ns(k, static_cast<int64_t>(source.size())), nt(k);
+    for (std::size_t i = 0; i < k; ++i) {
+        tp[i] = targets[i]->data();
+        nt[i] = static_cast<int64_t>(targets[i]->size());
+    }
+    std::vector<icpmi_config> cfgs(k, detail::to_c(config));
+    const std::size_t stride = static_cast<std::size_t>(config.max_iterations > 0 ? config.max_iterations : 0) + 1;
+    std::vector<double> hist(k * stride);
+    std::vector<icpmi_result> res(k);
+    std::vector<int32_t> status(k);
+    const int rc = icpmi_align_batch(ctx.get(), static_cast<int32_t>(k), sp.data(), ns.data(), tp.data(), nt.data(), cfgs.data(),
+                                     res.data(), hist.data(), static_cast<int32_t>(stride), status.data());
+    if (rc != ICPMI_OK) throw IcpError(rc, icpmi_last_error(ctx.get()));
+    for (std::size_t i = 0; i < k; ++i) {
+        std::array<double, 16> m;
+        for (int e = 0; e < 16; ++e) m[e] = res[i].transformation[e];
+        out[i].transformation = Transformation(m);
+        out[i].converged = res[i].converged != 0;
+        out[i].num_iterations = res[i].num_iterations;
+        out[i].final_error = res[i].final_error;
+        out[i].error_history.assign(hist.begin() + static_cast<std::ptrdiff_t>(i * stride),
+                                    hist.begin() + static_cast<std::ptrdiff_t>(i * stride) + res[i].history_len);
+    }
+    return out;
+}
+
 // Same call shape as slam::icp_point_to_plane (icp.hpp:157-161).
 inline ICPResult icp_point_to_plane(const PointCloud &source, const PointCloud &target,
                                     const ICPConfig &config = ICPConfig())
@@ -573,24 +608,35 @@ public:
             if (dist[i] < config_.sc_distance_threshold) candidates.emplace_back(dist[i], static_cast<int>(i)); // :86-89
         }
         std::sort(candidates.begin(), candidates.end()); // :93
+        // The reference verifies the candidates one after the other until max_candidates are ACCEPTED (:96-123).
+        // The registrations are independent: the next (max_candidates - accepted) of them, all of which the
+        // sequential loop would reach, run side by side (icpmi_align_batch); outcomes in the reference's order.
         int verified = 0;
-        for (const auto &cand : candidates) {
-            if (verified >= config_.max_candidates) break; // :97
-            ICPConfig icp;                                 // :102-105
-            icp.max_iterations = 30;
-            icp.tolerance = 1e-6;
-            const ICPResult r = icp_point_to_plane(*ctx_, clouds_[q].data(), clouds_[q].size(), clouds_[cand.second].data(),
-                                                   clouds_[cand.second].size(), icp);            // :109
-            if (r.converged && r.final_error < config_.icp_fitness_threshold) {                  // :112
-                LoopClosureResult out;
-                out.query_frame = frame_indices_[q];
-                out.match_frame = frame_indices_[cand.second];
-                out.transform = r.transformation;
-                out.scan_context_distance = cand.first;
-                out.icp_fitness = r.final_error;
-                results.push_back(out);
-                ++verified;
+        std::size_t pos = 0;
+        ICPConfig icp;                                     // :102-105
+        icp.max_iterations = 30;
+        icp.tolerance = 1e-6;
+        while (pos < candidates.size() && verified < config_.max_candidates) { // :97
+            const std::size_t take = std::min<std::size_t>(candidates.size() - pos,
+                                                           std::min<std::size_t>(static_cast<std::size_t>(config_.max_candidates - verified), ICPMI_MAX_BATCH));
+            std::vector<const PointCloud *> tg;
+            for (std::size_t i = 0; i < take; ++i) tg.push_back(&clouds_[static_cast<std::size_t>(candidates[pos + i].second)]);
+            const std::vector<ICPResult> rs = icp_point_to_plane_batch(*ctx_, clouds_[q], tg, icp); // :109
+            for (std::size_t i = 0; i < take; ++i) {
+                const ICPResult &r = rs[i];
+                const auto &cand = candidates[pos + i];
+                if (r.converged && r.final_error < config_.icp_fitness_threshold) {              // :112
+                    LoopClosureResult out;
+                    out.query_frame = frame_indices_[q];
+                    out.match_frame = frame_indices_[cand.second];
+                    out.transform = r.transformation;
+                    out.scan_context_distance = cand.first;
+                    out.icp_fitness = r.final_error;
+                    results.push_back(out);
+                    ++verified;
+                }
             }
+            pos += take;
         }
         return results;
     }

@@ -18,7 +18,7 @@ UNIQUE_ID_BYTES = 128
 
 EXPORTS = [
     "icpmi_version", "icpmi_options_default", "icpmi_config_default", "icpmi_create",
-    "icpmi_destroy", "icpmi_last_error", "icpmi_align", "icpmi_align_device",
+    "icpmi_destroy", "icpmi_last_error", "icpmi_align", "icpmi_align_device", "icpmi_align_batch",
     "icpmi_nearest_batch", "icpmi_k_nearest", "icpmi_estimate_normals", "icpmi_solve_point_to_plane",
     "icpmi_transform_points", "icpmi_comm_unique_id", "icpmi_comm_init", "icpmi_comm_finalize",
     "icpmi_comm_init_callbacks", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
@@ -152,6 +152,8 @@ def load_library(path=None):
                               C.POINTER(Result), dp, C.c_int32]
     L.icpmi_align_device.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.POINTER(Config),
                                      C.POINTER(Result), dp, C.c_int32]
+    L.icpmi_align_batch.argtypes = [vp, C.c_int32, C.POINTER(dp), C.POINTER(C.c_int64), C.POINTER(dp), C.POINTER(C.c_int64),
+                                    C.POINTER(Config), C.POINTER(Result), dp, C.c_int32, C.POINTER(C.c_int32)]
     L.icpmi_nearest_batch.argtypes = [vp, dp, C.c_int64, dp, C.c_int64, C.POINTER(C.c_int32), dp]
     L.icpmi_k_nearest.argtypes = [vp, dp, C.c_int64, dp, C.c_int64, C.c_int32, C.POINTER(C.c_int32), dp]
     L.icpmi_estimate_normals.argtypes = [vp, dp, C.c_int64, C.c_int32, dp]
@@ -281,6 +283,33 @@ class Context:
         self._check(self._lib.icpmi_align(self._h, _dp(src), src.shape[0], _dp(tgt), tgt.shape[0],
                                           C.byref(cfg), C.byref(res), _dp(hist), cap))
         return res, hist[:res.history_len].copy()
+
+    def align_batch(self, sources, targets, cfgs):
+        """Several independent registrations at once (icpmi_align_batch: the verifications of one
+        LoopClosureDetector::detect, loop_closure.hpp:94-123) -> [(Result, error history), ...], each
+        bit-identical to align() of the same pair.  cfgs: one Config for all, or one per pair."""
+        srcs, tgts = [_f64(a) for a in sources], [_f64(a) for a in targets]
+        k = len(srcs)
+        if k != len(tgts) or k < 1:
+            raise ValueError("as many targets as sources, at least one")
+        cfg_list = list(cfgs) if isinstance(cfgs, (list, tuple)) else [cfgs] * k
+        cfg_arr = (Config * k)(*cfg_list)
+        stride = max(c.max_iterations for c in cfg_list) + 1
+        hist = np.zeros((k, stride))
+        res = (Result * k)()
+        status = (C.c_int32 * k)()
+        dpp = C.POINTER(C.c_double)
+        sp = (dpp * k)(*[_dp(a) for a in srcs])
+        tp = (dpp * k)(*[_dp(a) for a in tgts])
+        ns = (C.c_int64 * k)(*[a.shape[0] for a in srcs])
+        nt = (C.c_int64 * k)(*[a.shape[0] for a in tgts])
+        self._check(self._lib.icpmi_align_batch(self._h, k, sp, ns, tp, nt, cfg_arr, res, _dp(hist), stride, status))
+        out = []
+        for i in range(k):
+            r = Result()
+            C.memmove(C.byref(r), C.byref(res[i]), C.sizeof(Result))
+            out.append((r, hist[i, :r.history_len].copy()))
+        return out
 
     def align_device(self, src_ptr, n_src, tgt_ptr, n_tgt, cfg):
         """src_ptr/tgt_ptr: device addresses of row-major N x 3 fp64 (e.g. tensor.data_ptr())."""

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -155,6 +156,19 @@ struct FilePrefetch {
     long files = 0;
 };
 
+// One more registration beside the caller's (icpmi_align_batch): a helper context -- stream, workspace -- and the
+// host thread that drives it (align_device spins on the device's progress words, so every concurrent
+// registration needs a host thread); the thread is kept between calls (starting one costs tens of microseconds,
+// a tenth of a small registration).
+struct BatchWorker {
+    icpmi_ctx *helper = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = false, quit = false;
+};
+
 struct icpmi_ctx {
     icpmi_options opt;
     hipStream_t stream = nullptr;
@@ -178,6 +192,7 @@ struct icpmi_ctx {
     int prep_m = 0, prep_engine = 0;
     bool prep_valid = false;
     hipEvent_t result_ready = nullptr;              // recorded behind a call's result copies (stream path)
+    bool trailing_work = false;                     // a push returned with the next target's preparation still queued
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     DevBuf src_sort, blk_lists, work;         // pruned engine: Morton order of the source, per-block split lists, unit list
@@ -208,6 +223,7 @@ struct icpmi_ctx {
     icpmi_allgather_fn cb_allgather = nullptr;
     void *cb_user = nullptr;
     std::vector<double> cb_host;
+    std::vector<BatchWorker *> helpers; // icpmi_align_batch: one more stream + workspace + host thread per concurrent registration
 };
 
 namespace {
@@ -730,6 +746,19 @@ int check_common(icpmi_ctx *ctx)
 {
     if (!ctx) return ICPMI_ERR_NULL;
     HIP_TRY(ctx, hipSetDevice(ctx->opt.device));
+    if (ctx->trailing_work) {
+        // The previous icpmi_stream_push* returned with the preparation of its NEXT target (Morton sort, operand
+        // packing, 20-NN, normals) still queued.  A fault in those kernels belongs to that step, not to whatever
+        // this call is about to do: look before queueing anything behind it.
+        ctx->trailing_work = false;
+        const hipError_t e = hipStreamQuery(ctx->stream);
+        if (e != hipSuccess && e != hipErrorNotReady) {
+            (void)hipGetLastError();
+            ctx->prep_valid = false;
+            return fail(ctx, ICPMI_ERR_HIP, "the target preparation queued behind the previous icpmi_stream_push failed: %s",
+                        hipGetErrorString(e));
+        }
+    }
     return ICPMI_OK;
 }
 
@@ -1098,7 +1127,12 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         // while the caller digests them (with profiling on, the stage timers want the whole stream drained)
         if (!ctx->result_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->result_ready, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventRecord(ctx->result_ready, s));
-        (void)before_wait(ctx); // (a failure there only means the next call prepares its target itself)
+        {   // (a failure there only means the next call prepares its target itself: it must not leave its text in
+            // the error string of a call that succeeded)
+            const std::string keep = ctx->err;
+            if (before_wait(ctx) != ICPMI_OK) ctx->err = keep;
+            ctx->trailing_work = true; // kernels of the NEXT call's target are queued behind this call's results
+        }
         HIP_TRY(ctx, hipEventSynchronize(ctx->result_ready));
     } else {
         HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -1165,6 +1199,7 @@ int voxel_filter_core(hipStream_t s, VoxelScratch vs, const double *d_pts, int n
     VOX_TRY(run_lengths_u64(nullptr, &b2, keys_out, (unsigned)n, uniq, counts, runs_d, s));
     VOX_TRY(exclusive_sum_u32(nullptr, &b3, counts, offsets, (unsigned)n, s));
     VOX_TRY(reserve_raw(*vs.tmp, std::max(b1, std::max(b2, b3))));
+    VOX_TRY(hipMemsetAsync(runs_d + 1, 0, sizeof(unsigned), s)); // the flag word: k_voxel_keys ORs into it
     hipLaunchKernelGGL(k_voxel_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_pts, n, voxel, (const VoxelBox *)box, runs_d + 1,
                        keys_in, vals_in);
     VOX_TRY(sort_pairs_u64(vs.tmp->p, &b1, keys_in, keys_out, vals_in, order, (unsigned)n, s));
@@ -1180,7 +1215,7 @@ int voxel_filter_core(hipStream_t s, VoxelScratch vs, const double *d_pts, int n
     VOX_TRY(hipMemcpyAsync(runs_flag, runs_d, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s)); // the call's one round trip
     VOX_TRY(hipStreamSynchronize(s));
     if (runs_flag[1]) {
-        *msg = "voxel grid spans more than 2^21 cells on an axis (or non-finite points)";
+        *msg = "voxel grid spans more than 2^21 cells on an axis, or a point has a non-finite coordinate";
         return ICPMI_ERR_ARG;
     }
     const unsigned runs = runs_flag[0];
@@ -1388,6 +1423,17 @@ void icpmi_destroy(icpmi_ctx *ctx)
         delete pf;
         ctx->prefetch = nullptr;
     }
+    for (BatchWorker *w : ctx->helpers) {
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->quit = true;
+        }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+        icpmi_destroy(w->helper);
+        delete w;
+    }
+    ctx->helpers.clear();
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
     for (DevBuf *b : {&ctx->cur, &ctx->nrm, &ctx->idx, &ctx->part_d2, &ctx->part_idx, &ctx->partials,
                       &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out, &ctx->src_sort, &ctx->blk_lists, &ctx->work,
@@ -1444,6 +1490,67 @@ int icpmi_align(icpmi_ctx *ctx, const double *source_xyz, int64_t n_src, const d
                                 hipMemcpyHostToDevice, ctx->stream));
     return align_device(ctx, (const double *)ctx->stage_b.p, n_src, (const double *)ctx->stage_c.p,
                         n_tgt, cfg, result, error_history, history_cap);
+}
+
+int icpmi_align_batch(icpmi_ctx *ctx, int32_t count, const double *const *sources_xyz, const int64_t *n_src,
+                      const double *const *targets_xyz, const int64_t *n_tgt, const icpmi_config *cfgs,
+                      icpmi_result *results, double *error_history, int32_t history_stride, int32_t *status)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!sources_xyz || !n_src || !targets_xyz || !n_tgt || !cfgs || !results || !error_history || !status)
+        return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    if (count < 1 || count > ICPMI_MAX_BATCH) return fail(ctx, ICPMI_ERR_ARG, "count %d outside [1,%d]", count, ICPMI_MAX_BATCH);
+    if (ctx->comm || ctx->cb_allreduce) return fail(ctx, ICPMI_ERR_ARG, "a context with a communicator registers one (sharded) problem at a time");
+    while ((int)ctx->helpers.size() < count - 1) { // grown once, kept: their workspaces are grow-only like ctx's own
+        icpmi_options o = ctx->opt;
+        o.profile = 0;
+        icpmi_ctx *h = nullptr;
+        if ((rc = icpmi_create(&o, &h))) return fail(ctx, rc, "helper context: %s", icpmi_last_error(nullptr));
+        BatchWorker *w = new BatchWorker();
+        w->helper = h;
+        w->th = std::thread([w] {
+            std::unique_lock<std::mutex> lk(w->mu);
+            for (;;) {
+                w->cv.wait(lk, [w] { return w->quit || w->has_job; });
+                if (w->quit) return;
+                lk.unlock();
+                w->job();
+                lk.lock();
+                w->has_job = false;
+                w->done = true;
+                w->cv.notify_all();
+            }
+        });
+        ctx->helpers.push_back(w);
+    }
+    auto run = [&](int k) {
+        icpmi_ctx *c = k == 0 ? ctx : ctx->helpers[(size_t)k - 1]->helper;
+        status[k] = icpmi_align(c, sources_xyz[k], n_src[k], targets_xyz[k], n_tgt[k], &cfgs[k], &results[k],
+                                error_history + (size_t)k * (size_t)history_stride, history_stride);
+    };
+    for (int k = 1; k < count; ++k) {
+        BatchWorker *w = ctx->helpers[(size_t)k - 1];
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->job = [&run, k] { run(k); };
+            w->done = false;
+            w->has_job = true;
+        }
+        w->cv.notify_all();
+    }
+    run(0);
+    for (int k = 1; k < count; ++k) {
+        BatchWorker *w = ctx->helpers[(size_t)k - 1];
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [w] { return w->done; });
+    }
+    for (int k = 0; k < count; ++k)
+        if (status[k] != ICPMI_OK) {
+            if (k > 0) ctx->err = ctx->helpers[(size_t)k - 1]->helper->err;
+            return status[k];
+        }
+    return ICPMI_OK;
 }
 
 int icpmi_nearest_batch(icpmi_ctx *ctx, const double *targets_xyz, int64_t n_tgt,
@@ -2138,10 +2245,13 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
             int rc2;
             if (pf->filtered_voxel[slot] > 0.0 && pf->filtered_voxel[slot] == voxel_size) {
                 // the worker filtered it too: its buffer becomes the current scan (ours goes to the worker in exchange;
-                // it holds the scan before the previous one, which nothing reads any more)
+                // it holds the scan before the previous one, which nothing reads any more).  The arguments are
+                // checked before anything is taken, and a registration that fails hands the buffer back: the
+                // frame stays in its slot and a second push of the path finds it.
                 if ((rc2 = stream_check_args(ctx, cfg, result, error_history, history_cap, info)) == ICPMI_OK) {
                     std::swap(ctx->stream_cur, pf->filtered[slot]);
                     rc2 = stream_register(ctx, pf->filtered_n[slot], min_points, cfg, result, error_history, history_cap, info);
+                    if (rc2 != ICPMI_OK) std::swap(ctx->stream_cur, pf->filtered[slot]);
                 }
                 std::lock_guard<std::mutex> lk2(pf->mu);
                 pf->voxel_hint = voxel_size;
@@ -2153,7 +2263,7 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
             if (!recorded) (void)hipStreamSynchronize(ctx->stream); // (then the slot is simply free)
             lk.lock();
             pf->slot_used[slot] = recorded;
-            pf->ready[slot].clear(); // free for the worker, behind the event
+            if (rc2 == ICPMI_OK) pf->ready[slot].clear(); // free for the worker, behind the event (a failed push leaves the frame there)
             pf->taking = -1;
             lk.unlock();
             return rc2;

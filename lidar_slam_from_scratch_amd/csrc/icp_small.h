@@ -9,7 +9,11 @@
 // in one launch and keeps the intermediate in LDS.  (Measured and dropped, scripts/small_clock.py:
 // four waves per workgroup with whole splits per wave -- fewer instructions in all, but one wave per
 // SIMD leaves every MFMA -> minimum dependency and every load exposed: 30k cycles against 21k; slot
-// scans by the whole wave with DPP reductions instead of quarter-waves: 6.4k cycles against 4.4k.)
+// scans by the whole wave with DPP reductions instead of quarter-waves: 6.4k cycles against 4.4k; the step of
+// the PREVIOUS pass -- k_finish_step's work -- repeated by every workgroup at the head of this kernel, so that
+// an iteration is one launch: 21.0 us per iteration against 20.3, the serial step does not hide under the
+// operand stream but in front of an issue-bound remainder, and 250 workgroups sitting through it keep a
+// second stream's kernels off the chip: 0.37 ms per frame of the file stream against 0.32.)
 //
 //   workgroup = 32 rows (one MFMA tile of queries) x ALL splits, 8 waves = two per SIMD.
 //   1. every wave loads the 32 rows and moves them by the pending pose update (icp.hpp:174-176

@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void k_widen_f32(const float *__restrict__ rec
 
 // The key origin (the cloud's minimum key per axis) comes from the bounding box the device has
 // just reduced: no round trip to the host for it.  `flag` (one word, read back with the run count)
-// is set when the grid cannot be keyed: non-finite points, or more than 2^21 cells on an axis.
+// is set (OR-ed into a word the caller has cleared) when the grid cannot be keyed: more than 2^21 cells on
+// an axis (an infinite coordinate included: it is in the box), or a point with a NaN coordinate -- the box's
+// comparisons skip a NaN, and the cast of floor(NaN / voxel) is undefined (in the reference too,
+// file_utils.cpp:177-179): its key could land in another voxel's bit fields and poison that centroid.
 struct VoxelBox { // same layout as NnFrame (nn_mfma.h)
     double lo[3], hi[3];
 };
@@ -49,13 +52,16 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const double *__restrict__ p
         bad |= !(lo == lo) || !(hi == hi) || hi - lo >= 2097152.0 || fabs(lo) > 4.0e18 || fabs(hi) > 4.0e18;
         k0[a] = bad ? 0 : (long long)lo;
     }
-    if (i == 0) *flag = bad ? 1u : 0u;
+    if (i == 0 && bad) atomicOr(flag, 1u);
     if (i >= n) return;
     unsigned long long key = 0ull;
-    if (!bad) {
-        const long long kx = (long long)floor(pts[3 * i] / voxel) - k0[0];       // file_utils.cpp:177
-        const long long ky = (long long)floor(pts[3 * i + 1] / voxel) - k0[1];   // file_utils.cpp:178
-        const long long kz = (long long)floor(pts[3 * i + 2] / voxel) - k0[2];   // file_utils.cpp:179
+    const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    if (!(px == px) || !(py == py) || !(pz == pz)) {
+        atomicOr(flag, 1u);
+    } else if (!bad) {
+        const long long kx = (long long)floor(px / voxel) - k0[0];   // file_utils.cpp:177
+        const long long ky = (long long)floor(py / voxel) - k0[1];   // file_utils.cpp:178
+        const long long kz = (long long)floor(pz / voxel) - k0[2];   // file_utils.cpp:179
         key = ((unsigned long long)kx << 42) | ((unsigned long long)ky << 21) | (unsigned long long)kz;
     }
     keys[i] = key;

@@ -46,6 +46,23 @@ class GpuBackend:
         from .odometry import gpu_align
         return gpu_align(self.ctx)(source, target, max_iterations, tolerance)
 
+    def align_many(self, source, targets, max_iterations, tolerance):
+        """The verifications of one detect() side by side on the GPU (icpmi_align_batch): same results as
+        align() one after the other."""
+        from . import capi
+
+        class _R:
+            pass
+
+        cfg = capi.Context.make_config(max_iterations=max_iterations, tolerance=tolerance)
+        out = []
+        for res, _hist in self.ctx.align_batch([source] * len(targets), targets, cfg):
+            r = _R()
+            r.transformation = np.array(res.transformation[:]).reshape(4, 4)
+            r.converged, r.final_error, r.num_iterations = bool(res.converged), res.final_error, res.num_iterations
+            out.append(r)
+        return out
+
 
 class LoopClosureDetector:
     """loop_closure.hpp:41-148"""
@@ -84,13 +101,22 @@ class LoopClosureDetector:
             if dist[i] < self.config.sc_distance_threshold:                   # :87-89
                 candidates.append((float(dist[i]), i))
         candidates.sort()                                                     # :93
-        verified = 0
-        for sc_dist, cand in candidates:
-            if verified >= self.config.max_candidates:                        # :97
-                break
-            r = self.backend.align(self._clouds[q], self._clouds[cand], 30, 1e-6)   # :102-109
-            if r.converged and r.final_error < self.config.icp_fitness_threshold:   # :112
-                results.append(LoopClosureResult(self._frame_indices[q], self._frame_indices[cand],
-                                                 np.asarray(r.transformation), sc_dist, r.final_error))
-                verified += 1
+        # The reference verifies the candidates one after the other until max_candidates are ACCEPTED (:96-123).
+        # The registrations are independent, so the next (max_candidates - accepted) of them -- all of which the
+        # sequential loop would reach -- run side by side when the backend can (icpmi_align_batch); the
+        # outcomes are taken in the reference's order.
+        verified, pos = 0, 0
+        many = getattr(self.backend, "align_many", None)
+        while pos < len(candidates) and verified < self.config.max_candidates:   # :97
+            chunk = candidates[pos:pos + (self.config.max_candidates - verified)]
+            pos += len(chunk)
+            if many is not None and len(chunk) > 1:
+                outs = many(self._clouds[q], [self._clouds[c] for _, c in chunk], 30, 1e-6)
+            else:
+                outs = [self.backend.align(self._clouds[q], self._clouds[c], 30, 1e-6) for _, c in chunk]   # :102-109
+            for (sc_dist, cand), r in zip(chunk, outs):
+                if r.converged and r.final_error < self.config.icp_fitness_threshold:   # :112
+                    results.append(LoopClosureResult(self._frame_indices[q], self._frame_indices[cand],
+                                                     np.asarray(r.transformation), sc_dist, r.final_error))
+                    verified += 1
         return results

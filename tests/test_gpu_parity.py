@@ -290,9 +290,16 @@ def test_voxel_downsample_lidar_frame_and_edge_cases(gpu_ctx, oracle):
     with pytest.raises(capi.IcpError) as e:                              # > 2^21 cells on an axis
         gpu_ctx.voxel_downsample(np.array([[0.0, 0, 0], [1e7, 0, 0]]), 1e-3)
     assert e.value.code == capi.ERR_ARG
-    # a NaN point is UB in the reference (cast of floor(NaN)); here it must only be harmless
-    out = gpu_ctx.voxel_downsample(np.array([[0.1, 0, 0], [np.nan, 0, 0], [0.2, 0, 0]]), 0.5)
-    assert 1 <= out.shape[0] <= 3
+    # a NaN or infinite coordinate is UB in the reference (cast of floor(NaN)): here it is an error, never a key that
+    # lands in another voxel's bit fields; the context stays usable
+    for bad in (np.nan, np.inf, -np.inf):
+        for col in range(3):
+            pts = np.array([[0.1, 0, 0], [0.3, 0.2, 0.1], [0.2, 0, 0]])
+            pts[1, col] = bad
+            with pytest.raises(capi.IcpError) as e:
+                gpu_ctx.voxel_downsample(pts, 0.5)
+            assert e.value.code == capi.ERR_ARG
+    assert (gpu_ctx.voxel_downsample(edge, 0.5) == oracle.voxel_downsample(edge, 0.5)).all()
     # small and large grids: 13+13+13 bits of cell offsets, 14+14+13, 17+17+17, and one axis at its 21-bit limit
     rng = np.random.default_rng(77)
     for extent, voxel in (((4.0, 4.0, 4.0), 1e-3), ((8.0, 8.0, 4.0), 1e-3), ((100.0, 100.0, 100.0), 1e-3),
@@ -741,7 +748,8 @@ def test_pruned_engine_skips_blocks_and_keeps_the_result(case, oracle):
         full.close()
         pruned.close()
     assert q["nn_pruned_blocks"] == 0 and q["nn_coarse_blocks"] > 0
-    assert p["nn_coarse_blocks"] == q["nn_coarse_blocks"]
+    if case != "lidar_pair":   # (a run that converges queues a pass or two beyond its end, how many is a matter of timing)
+        assert p["nn_coarse_blocks"] == q["nn_coarse_blocks"]
     if case == "c3_small_20k":
         assert p["nn_pruned_blocks"] > 0.3 * p["nn_coarse_blocks"], p
     elif case == "lidar_pair":   # ~3000-point frames: few, large blocks -- some culling only
@@ -976,3 +984,35 @@ print(json.dumps(out))
     assert legs["0"].pop("small_launches") == 0 and legs["1"].pop("small_launches") > 20
     assert legs["0"] == legs["1"]
     assert all(v["iters"] >= 1 for v in legs["1"].values())
+
+
+def test_align_batch_is_the_sequential_calls(gpu_ctx):
+    """icpmi_align_batch: the up-to-three verifications of one LoopClosureDetector::detect
+    (loop_closure.hpp:94-123) side by side, each on a stream and workspace of its own.  Every result must
+    be BIT-identical to the same registration made alone; a problem that fails (empty target) reports
+    its own status and the call returns it; the context stays usable."""
+    q = synth.lidar_frame(1, beams=32, azimuths=900)
+    tgts = [synth.lidar_frame(f, beams=32, azimuths=900) for f in (0, 2, 3)]
+    cfg = capi.Context.make_config(max_iterations=30, tolerance=1e-6)     # loop_closure.hpp:105-107
+    alone = [gpu_ctx.align(q, t, cfg) for t in tgts]
+    for rep in range(2):                                                  # (second time: helper contexts already there)
+        both = gpu_ctx.align_batch([q] * 3, tgts, cfg)
+        for (ra, ha), (rb, hb) in zip(alone, both):
+            assert tuple(ra.transformation) == tuple(rb.transformation) and (ha == hb).all()
+            assert (ra.converged, ra.num_iterations, ra.final_error) == (rb.converged, rb.num_iterations, rb.final_error)
+    # different sources and per-problem configs; one problem
+    s2 = synth.c1_room_corner(3000)
+    cfgs = [capi.Context.make_config(max_iterations=5, tolerance=0.0, min_error=0.0), cfg]
+    two = gpu_ctx.align_batch([s2[0], q], [s2[1], tgts[0]], cfgs)
+    r0, h0 = gpu_ctx.align(s2[0], s2[1], cfgs[0])
+    assert tuple(two[0][0].transformation) == tuple(r0.transformation) and (two[0][1] == h0).all() and two[0][0].num_iterations == 5
+    assert tuple(two[1][0].transformation) == tuple(alone[0][0].transformation)
+    one = gpu_ctx.align_batch([q], [tgts[1]], cfg)
+    assert tuple(one[0][0].transformation) == tuple(alone[1][0].transformation)
+    with pytest.raises(capi.IcpError) as e:
+        gpu_ctx.align_batch([q, q], [tgts[0], np.zeros((0, 3))], cfg)
+    assert e.value.code == capi.ERR_EMPTY_TARGET
+    with pytest.raises(capi.IcpError):
+        gpu_ctx.align_batch([q] * 9, [tgts[0]] * 9, cfg)                  # more than ICPMI_MAX_BATCH
+    again = gpu_ctx.align(q, tgts[2], cfg)
+    assert tuple(again[0].transformation) == tuple(alone[2][0].transformation)

@@ -330,3 +330,33 @@ def test_c5_stream_at_stream_length(tmp_path, oracle):
     assert abs(ate_g - ate_c) < 1e-6
     print("C5 stand-in, 200 frames: %d iterations, %d gated, worst pose delta %.2e m / %.2e rad, ATE %.7f / %.7f m"
           % (sum(tr.iterations), sum(tr.gated), worst_t, worst_r, ate_g, ate_c))
+
+
+def test_failed_push_leaves_the_prefetched_frame(tmp_path):
+    """a push of a prefetched-and-filtered file that fails (here: arguments the call rejects) must not
+    consume the frame -- its filtered copy is not swapped away and the slot stays taken -- so that the same
+    push, repeated with good arguments, gives what an undisturbed stream gives."""
+    import run_sequence
+    run_sequence.write_synthetic_drive(str(tmp_path), 0, 4, beams=32, azimuths=900)
+    paths = [p for _, p in capi.discover_frames(str(tmp_path))]
+    ctx = capi.Context(device=0)
+    want = odometry.run_odometry_stream(paths, ctx, prefetch=True)
+    cfg = capi.Context.make_config()
+    bad = capi.Context.make_config(max_iterations=-1)
+    ctx.stream_reset()
+    its = []
+    for k, p in enumerate(paths):
+        if k + 1 < len(paths):
+            ctx.stream_prefetch_file(paths[k + 1])
+        if k == 2:
+            with pytest.raises(capi.IcpError) as e:
+                ctx.stream_push_file(p, 0.5, 1000, bad)
+            assert e.value.code == capi.ERR_ARG
+        res, _, info = ctx.stream_push_file(p, 0.5, 1000, cfg)
+        if info.status == capi.STREAM_REGISTERED:
+            its.append((res.num_iterations, tuple(res.transformation)))
+    assert [i for i, _ in its] == want.iterations
+    for (_, T), d in zip(its, want.deltas):
+        if not (d == np.eye(4)).all():
+            assert (np.array(T).reshape(4, 4) == d).all()
+    ctx.close()
