@@ -185,6 +185,7 @@ struct icpmi_ctx {
     DevBuf grid_set, grid_in, grid_out, grid_cnt, world; // occupancy grid: the set (sorted unique keys), {set, new keys}, sorted, run data; world points
     int64_t grid_n = 0;                             // cells in grid_set
     unsigned *h_grid = nullptr;                     // pinned: the set's size on its way back
+    unsigned long long *h_cnt = nullptr;            // pinned: the resolve's counters on their way back (profiling)
     FilePrefetch *prefetch = nullptr;               // worker reading the next frame file (icpmi_stream_prefetch_file)
     // the target whose search structure and normals the context's buffers currently hold (prepare_target):
     // icpmi_stream_push prepares the NEXT frame's target while the caller is still busy with this frame's result
@@ -629,6 +630,9 @@ int reduce_blocks(const icpmi_ctx *ctx, int n)
     return std::max(1, std::min(ctx->cu_count, (n + 255) / 256));
 }
 
+#ifndef ICPMI_KNN_CHUNK_DEFAULT_MB
+#define ICPMI_KNN_CHUNK_DEFAULT_MB 1024
+#endif
 // k-NN lists of rows [row0,row1) of d_qry among the m points d_pts (kdtree.hpp:65-78): MFMA
 // coarse pass + exact resolve, or the exact fp64 kernel.  List of row i -> ctx->knn_idx[i * k ..],
 // closest first.  prepare_nn() must have run for d_pts.  d_qry == d_pts for normal estimation.
@@ -654,7 +658,17 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
         // bound the slot-minimum buffer (2 B x nslots per row) by chunking the rows: ~1 GiB, or
         // ~4 GiB when culling leaves most of it untouched (the pruned engine writes only the
         // listed splits of a row, the layout stays dense)
-        const long budget = by_sorted_row ? (4l << 30) : (1l << 30);
+        // (ICPMI_KNN_CHUNK_MB: the all-pairs budget in MiB, for tuning runs.  The buffer is written by the MODE-1 coarse
+        // pass and read once by k_knn_resolve: a chunk that fits the 256 MB Infinity Cache beside the target never
+        // goes to HBM between the two)
+        static const long knn_budget = [] {
+            if (const char *e = getenv("ICPMI_KNN_CHUNK_MB")) {
+                const long x = strtol(e, nullptr, 10);
+                if (x >= 1 && x <= 16384) return x << 20;
+            }
+            return (long)ICPMI_KNN_CHUNK_DEFAULT_MB << 20;
+        }();
+        const long budget = by_sorted_row ? (4l << 30) : knn_budget;
         long chunk = (budget / ((long)nslots * 2)) / kCoarseQueries * kCoarseQueries; // 2 bytes per slot minimum (bf16)
         chunk = std::max<long>(kCoarseQueries, std::min<long>(chunk, ((long)rows + kCoarseQueries - 1) / kCoarseQueries * kCoarseQueries));
         if ((rc = reserve(ctx, ctx->slotmin, sizeof(unsigned short) * (size_t)chunk * nslots))) return rc;
@@ -1122,6 +1136,14 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     }
     HIP_TRY(ctx, hipMemcpyAsync(hs, st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     if (hcopy > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_hist, hist, sizeof(double) * (size_t)hcopy, hipMemcpyDeviceToHost, s));
+    // profiling: the resolve's counters come back behind the same wait, and the events are read when somebody asks
+    // for the profile (icpmi_get_profile) -- a blocking copy and a dozen hipEventElapsedTime calls inside every
+    // call were ~0.1 ms of host time in a 9 ms C3 call, charged to the very thing they measure
+    const bool counters_back = ctx->opt.profile && ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && ctx->nn_misc.p;
+    if (counters_back) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cnt, (char *)ctx->nn_misc.p + 128, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemsetAsync((char *)ctx->nn_misc.p + 128, 0, 3 * sizeof(unsigned long long), s));
+    }
     if (before_wait && ctx->opt.profile == 0) {
         // the results are waited for through an event; what before_wait queues behind it keeps the device busy
         // while the caller digests them (with profiling on, the stage timers want the whole stream drained)
@@ -1140,7 +1162,12 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     HIP_TRY(ctx, hipGetLastError());
     const int hl = std::min(hs->hist_len, max_hist);
     if (hl > 0) memcpy(error_history, ctx->h_hist, sizeof(double) * (size_t)std::min(hl, history_cap));
-    harvest_profile(ctx);
+    if (counters_back) {
+        ctx->prof.nn_recheck_queries += (int64_t)ctx->h_cnt[0];
+        ctx->prof.nn_fallback_queries += (int64_t)ctx->h_cnt[1];
+        ctx->prof.nn_pruned_blocks += (int64_t)ctx->h_cnt[2];
+    }
+    if (ctx->ev_used > 4096) harvest_profile(ctx); // (otherwise when the profile is asked for)
     if (hs->error)
         return fail(ctx, ICPMI_ERR_RCCL, "the ranks of this sharded run disagreed on the end of the loop "
                                          "(different icpmi_config per rank, or an exchange that is not bit-identical on every rank)");
@@ -1389,6 +1416,7 @@ int icpmi_create(const icpmi_options *opt, icpmi_ctx **out)
     if (hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
     if (hipHostMalloc((void **)&ctx->h_flags, sizeof(int32_t) * kFlagRing, hipHostMallocMapped) != hipSuccess) return bail("hipHostMalloc");
     if (hipHostMalloc((void **)&ctx->h_grid, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
+    if (hipHostMalloc((void **)&ctx->h_cnt, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
     memset(ctx->h_flags, 0, sizeof(int32_t) * kFlagRing);
     if (hipHostGetDevicePointer((void **)&ctx->d_flags, ctx->h_flags, 0) != hipSuccess) return bail("hipHostGetDevicePointer");
     *out = ctx;
@@ -1443,6 +1471,7 @@ void icpmi_destroy(icpmi_ctx *ctx)
                       &ctx->grid_in, &ctx->grid_out, &ctx->grid_cnt, &ctx->world})
         release(*b);
     if (ctx->h_grid) (void)hipHostFree(ctx->h_grid);
+    if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
     if (ctx->result_ready) (void)hipEventDestroy(ctx->result_ready);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -2543,6 +2572,11 @@ int icpmi_comm_finalize(icpmi_ctx *ctx)
 int icpmi_reset_profile(icpmi_ctx *ctx)
 {
     if (!ctx) return ICPMI_ERR_NULL;
+    if (ctx->ev_used) { // events of finished calls not read yet: they belong to what is being discarded
+        (void)hipSetDevice(ctx->opt.device);
+        (void)hipStreamSynchronize(ctx->stream);
+        harvest_profile(ctx);
+    }
     memset(&ctx->prof, 0, sizeof(ctx->prof));
     return ICPMI_OK;
 }
@@ -2550,6 +2584,11 @@ int icpmi_reset_profile(icpmi_ctx *ctx)
 int icpmi_get_profile(icpmi_ctx *ctx, icpmi_profile *out)
 {
     if (!ctx || !out) return ICPMI_ERR_NULL;
+    if (ctx->ev_used) { // the events of the calls since the last look are read now (see align_device)
+        (void)hipSetDevice(ctx->opt.device);
+        (void)hipStreamSynchronize(ctx->stream);
+        harvest_profile(ctx);
+    }
     *out = ctx->prof;
     return ICPMI_OK;
 }
