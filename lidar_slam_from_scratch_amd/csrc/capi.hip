@@ -131,8 +131,16 @@ struct FilePrefetch {
     std::condition_variable cv;
     std::string want;         // path being read (valid while `busy`)
     std::string ready[2];     // per device slot: the path whose points wait there for the push of that path
-    void *h_buf = nullptr;    // pinned staging (the worker's alone)
-    size_t h_cap = 0;
+    void *h_buf[2] = {nullptr, nullptr};   // pinned staging, one per device slot (the worker's alone)
+    size_t h_cap[2] = {0, 0};
+    // The worker does not wait for its own GPU work: it records `filled[slot]` behind the copies, the widening and the
+    // filter and announces the file; the push of that file waits for the event and reads the filter's outcome (number
+    // of voxels, range flag) from pinned memory.  The worker's host time per file is then the read alone.
+    hipEvent_t filled[2] = {nullptr, nullptr};
+    unsigned *h_runs = nullptr;            // pinned: per slot {voxels, flag}
+    bool pending[2] = {false, false};      // announced, event not yet waited for
+    bool pend_filtered[2] = {false, false};
+    double pend_voxel[2] = {0.0, 0.0};
     void *d_f32[2] = {nullptr, nullptr};   // device: the float32 records as read
     double *d_raw[2] = {nullptr, nullptr}; // device: N x 3 fp64 raw points
     size_t d_cap[2] = {0, 0};              // records each slot holds
@@ -194,6 +202,12 @@ struct icpmi_ctx {
     bool prep_valid = false;
     hipEvent_t result_ready = nullptr;              // recorded behind a call's result copies (stream path)
     bool trailing_work = false;                     // a push returned with the next target's preparation still queued
+    // odometry stream: the NEXT target's search structure and normals are built on a stream and workspace of their
+    // own (a helper context) BESIDE the registration of the current frame, and adopted by swapping buffers
+    icpmi_ctx *prep_helper = nullptr;
+    hipEvent_t prep_done = nullptr;                 // recorded on the helper's stream behind a preparation
+    hipEvent_t scan_ready = nullptr;                // recorded on this context's stream behind the filter of the scan to prepare
+    bool helper_busy = false;                       // a preparation is queued on the helper and nothing has waited for it yet
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     DevBuf src_sort, blk_lists, work;         // pruned engine: Morton order of the source, per-block split lists, unit list
@@ -856,6 +870,29 @@ int sort_normals(icpmi_ctx *ctx, int m)
     return ICPMI_OK;
 }
 
+// A target prepared on a helper context (prepare_target on its stream and workspace) becomes this context's:
+// the buffers that DEFINE a prepared target change hands (the helper gets this context's old ones to build the
+// next target in), scratch stays where it is.  The caller orders this context's stream behind the helper's work.
+void adopt_target(icpmi_ctx *ctx, icpmi_ctx *h)
+{
+    std::swap(ctx->bpack, h->bpack);
+    std::swap(ctx->nn_misc, h->nn_misc);       // the target's frame (+ counters, + the voxel filter's box: scratch)
+    std::swap(ctx->sort_keys, h->sort_keys);   // holds the Morton permutation
+    std::swap(ctx->tgt_sorted, h->tgt_sorted);
+    std::swap(ctx->frames, h->frames);
+    std::swap(ctx->nrm, h->nrm);
+    std::swap(ctx->nrm_sorted, h->nrm_sorted);
+    ctx->nn_splits = h->nn_splits;
+    ctx->nn_ms = h->nn_ms;
+    ctx->nn_engine = h->nn_engine;
+    ctx->nn_pruned = h->nn_pruned;
+    ctx->prep_tgt = h->prep_tgt;
+    ctx->prep_m = h->prep_m;
+    ctx->prep_engine = h->prep_engine;
+    ctx->prep_valid = true;
+    h->prep_valid = false;
+}
+
 // ---- the ICP call, device pointers -----------------------------------------------------
 // Search structure + normals of a target for a single-GPU registration (icp.hpp:169-171), queued on the
 // context's stream; remembered, so that an align against the same device pointer and size with the
@@ -881,7 +918,8 @@ int prepare_target(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
 // for that event only (icpmi_stream_push prepares the next frame's target there).
 int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const double *d_tgt,
                  int64_t n_tgt64, const icpmi_config *cfg, icpmi_result *result,
-                 double *error_history, int32_t history_cap, int (*before_wait)(icpmi_ctx *) = nullptr)
+                 double *error_history, int32_t history_cap, int (*before_wait)(icpmi_ctx *) = nullptr,
+                 int (*after_first)(icpmi_ctx *) = nullptr)
 {
     const int n = (int)n_src64, m = (int)n_tgt64;
     const int max_it = cfg->max_iterations;
@@ -1096,7 +1134,14 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     StageTimer *t_loop = new StageTimer(ctx, ST_LOOP);
     struct Closer2 { StageTimer *&p; ~Closer2() { delete p; p = nullptr; } } close_loop{t_loop};
     for (int i = 0; i < kFlagRing; ++i) ctx->h_flags[i] = 0;
+    // `after_first` (may be null): called once the first iterations are queued and before the host first waits for
+    // the device -- what it queues (on another stream) costs the host its launch time while the device is busy
+    bool after_first_done = after_first == nullptr;
     for (int it = 0; it < max_it; ++it) {
+        if (it >= kLag && !after_first_done) {
+            after_first_done = true;
+            (void)after_first(ctx); // (a failure there only means the next call prepares its target itself)
+        }
         if (it >= kLag) {
             // wait until iteration it - kLag has reported; stop queueing once the loop has ended
             const int slot = (it - kLag) % kFlagRing, want = it - kLag + 1;
@@ -1119,6 +1164,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // post-loop evaluation (icp.hpp:235-252): a full pass after exhaustion, a re-statement
     // of the last error after a convergence break
     if ((rc = iteration(1, nullptr, 0))) return rc;
+    if (!after_first_done) (void)after_first(ctx);
     delete t_loop;
     t_loop = nullptr;
     delete t_total;
@@ -1195,8 +1241,11 @@ struct VoxelScratch {
 // `deferred` (the prefetch worker; implies `finish`): nothing waits for the number of voxels in the middle -- the
 // prefix sum runs over all n counts, the centroid kernel is launched for min(n, out_cap) voxels and reads the
 // number itself -- and count and range flag come back behind the centroids, with the call's only wait.
+// `async_out` (pinned, two words; with `deferred` only): nothing is waited for at all -- run count and range flag are
+// copied there behind the centroids and the CALLER looks at them once it has waited for the stream (the prefetch
+// worker: the push of the file does); *n_out is then left alone.
 int voxel_filter_core(hipStream_t s, VoxelScratch vs, const double *d_pts, int n, double voxel, double *d_out, int64_t out_cap,
-                      int64_t *n_out, bool finish, const char **msg, bool deferred = false)
+                      int64_t *n_out, bool finish, const char **msg, bool deferred = false, unsigned *async_out = nullptr)
 {
 #define VOX_TRY(call)                                   \
     do {                                                \
@@ -1238,6 +1287,10 @@ int voxel_filter_core(hipStream_t s, VoxelScratch vs, const double *d_pts, int n
         hipLaunchKernelGGL(k_voxel_centroids, dim3((bound + 3) / 4), dim3(256), 0, s, d_pts, (const unsigned *)order,
                            (const unsigned *)offsets, (const unsigned *)counts, bound, d_out, (const unsigned *)runs_d);
         VOX_TRY(hipGetLastError());
+    }
+    if (deferred && async_out) {
+        VOX_TRY(hipMemcpyAsync(async_out, runs_d, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        return ICPMI_OK;
     }
     VOX_TRY(hipMemcpyAsync(runs_flag, runs_d, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s)); // the call's one round trip
     VOX_TRY(hipStreamSynchronize(s));
@@ -1438,8 +1491,11 @@ void icpmi_destroy(icpmi_ctx *ctx)
         if (getenv("ICPMI_PREFETCH_STATS") && pf->files > 0)
             fprintf(stderr, "prefetch worker, ms per file over %ld files: wait for slot %.4f, open + read (first half on its way) %.4f, queueing %.4f, filter + wait %.4f\n",
                     pf->files, pf->t_wait / pf->files, pf->t_read / pf->files, pf->t_upload / pf->files, pf->t_filter / pf->files);
-        if (pf->h_buf) (void)hipHostFree(pf->h_buf);
+        if (pf->stream) (void)hipStreamSynchronize(pf->stream);
+        if (pf->h_runs) (void)hipHostFree(pf->h_runs);
         for (int k = 0; k < 2; ++k) {
+            if (pf->h_buf[k]) (void)hipHostFree(pf->h_buf[k]);
+            if (pf->filled[k]) (void)hipEventDestroy(pf->filled[k]);
             if (pf->d_f32[k]) (void)hipFree(pf->d_f32[k]);
             if (pf->d_raw[k]) (void)hipFree(pf->d_raw[k]);
         }
@@ -1451,6 +1507,10 @@ void icpmi_destroy(icpmi_ctx *ctx)
         delete pf;
         ctx->prefetch = nullptr;
     }
+    if (ctx->prep_helper) icpmi_destroy(ctx->prep_helper);
+    ctx->prep_helper = nullptr;
+    if (ctx->prep_done) (void)hipEventDestroy(ctx->prep_done);
+    if (ctx->scan_ready) (void)hipEventDestroy(ctx->scan_ready);
     for (BatchWorker *w : ctx->helpers) {
         {
             std::lock_guard<std::mutex> lk(w->mu);
@@ -2036,6 +2096,7 @@ int icpmi_stream_reset(icpmi_ctx *ctx)
     if (!ctx) return ICPMI_ERR_NULL;
     ctx->stream_prev_n = -1;
     ctx->prep_valid = false;
+    if (ctx->prep_helper) ctx->prep_helper->prep_valid = false; // (a preparation still in flight is waited for by the next push)
     return ICPMI_OK;
 }
 
@@ -2086,13 +2147,50 @@ int stream_register(icpmi_ctx *ctx, int64_t n_cur, int64_t min_points, const icp
     info->n_target = ctx->stream_prev_n < 0 ? 0 : ctx->stream_prev_n;
     ctx->stream_cur_n = n_cur;
     // The scan just filtered is the NEXT push's target (slam_node.cpp:128,152): its search structure and
-    // normals are queued now -- behind this push's registration, before the host waits for its result --
-    // so that the device builds them while the caller digests this frame (pose update, map, next file);
-    // the next push finds them in place (align_device: `prepared`).
+    // normals (Morton sort, split frames, operand packing, 20-NN, PCA: ~135 us of small kernels) are built on a
+    // helper context -- a stream and workspace of their own -- BESIDE this push's registration, queued once the
+    // registration's first iterations are (the host's launch time for them then hides behind the device's
+    // work), and the next push adopts them by swapping buffers behind an event: this context's stream carries the
+    // registration only.  (Round 2 queued the preparation on this stream behind the result: registration and
+    // preparation in a row were the 0.31 ms of a frame.)
+    const bool early = ctx->opt.profile == 0 && !(ctx->comm != nullptr || ctx->cb_allreduce != nullptr);
+    if (early && !ctx->prep_helper) {
+        icpmi_options o = ctx->opt;
+        icpmi_ctx *h = nullptr;
+        if (icpmi_create(&o, &h) == ICPMI_OK) ctx->prep_helper = h;
+        if (ctx->prep_helper && !ctx->prep_done) (void)hipEventCreateWithFlags(&ctx->prep_done, hipEventDisableTiming);
+        if (ctx->prep_helper && !ctx->scan_ready) (void)hipEventCreateWithFlags(&ctx->scan_ready, hipEventDisableTiming);
+    }
+    icpmi_ctx *helper = early && ctx->prep_done && ctx->scan_ready ? ctx->prep_helper : nullptr;
+    // everything that produced the scan on this context's stream is queued by now: the helper's stream waits for it
+    if (helper && n_cur > 0) HIP_TRY(ctx, hipEventRecord(ctx->scan_ready, ctx->stream));
     auto prepare_next = [](icpmi_ctx *c) -> int {
-        if (c->stream_cur_n <= 0 || (c->comm != nullptr || c->cb_allreduce != nullptr)) return ICPMI_OK;
-        return prepare_target(c, (const double *)c->stream_cur.p, (int)c->stream_cur_n, (int)c->stream_cur_n);
+        icpmi_ctx *h = c->prep_helper;
+        if (!h || c->stream_cur_n <= 0) return ICPMI_OK;
+        if (hipStreamWaitEvent(h->stream, c->scan_ready, 0) != hipSuccess) return ICPMI_ERR_HIP;
+        const int r = prepare_target(h, (const double *)c->stream_cur.p, (int)c->stream_cur_n, (int)c->stream_cur_n);
+        c->helper_busy = true; // (whatever was queued reads the scan: somebody has to wait for it before the scan's buffer is reused)
+        if (r != ICPMI_OK || hipEventRecord(c->prep_done, h->stream) != hipSuccess) {
+            h->prep_valid = false;
+            (void)hipStreamSynchronize(h->stream);
+            c->helper_busy = false;
+            return ICPMI_ERR_HIP;
+        }
+        return ICPMI_OK;
     };
+    // the target of THIS registration: prepared by the helper during the previous push?  Adopt it.
+    if (helper && helper->prep_valid && ctx->stream_prev_n > 0 && helper->prep_tgt == (const double *)ctx->stream_prev.p &&
+        helper->prep_m == (int)ctx->stream_prev_n) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->prep_done, 0));
+        adopt_target(ctx, helper);
+        ctx->helper_busy = false; // (this push's registration runs behind it, and the push waits for the registration)
+    } else if (ctx->helper_busy) {
+        // a preparation nobody is going to use (another scan was pushed in between, a stream reset): it still reads a
+        // scan buffer of this stream -- wait for it before anything is queued that could write there
+        HIP_TRY(ctx, hipEventSynchronize(ctx->prep_done));
+        ctx->helper_busy = false;
+        if (helper) helper->prep_valid = false;
+    }
     bool queued_next = false;
     if (ctx->stream_prev_n < 0) {
         info->status = ICPMI_STREAM_FIRST_FRAME;          // slam_node.cpp:69-72: nothing to register against yet
@@ -2100,14 +2198,15 @@ int stream_register(icpmi_ctx *ctx, int64_t n_cur, int64_t min_points, const icp
         info->status = ICPMI_STREAM_TOO_FEW_POINTS;       // slam_node.cpp:125-130: the caller repeats its last pose
     } else {
         // source = curr, target = prev (slam_node.cpp:132-133): both already in HBM; the target's
-        // search structure and normals are built from the resident copy (by the previous push, as a rule)
+        // search structure and normals are the adopted ones (prepared during the previous push, as a rule)
         info->status = ICPMI_STREAM_REGISTERED;
-        queued_next = ctx->opt.profile == 0;
+        queued_next = helper != nullptr;
         if ((rc = align_device(ctx, (const double *)ctx->stream_cur.p, n_cur, (const double *)ctx->stream_prev.p,
-                               ctx->stream_prev_n, cfg, result, error_history, history_cap, +prepare_next)))
+                               ctx->stream_prev_n, cfg, result, error_history, history_cap, nullptr,
+                               helper ? +prepare_next : nullptr)))
             return rc;
     }
-    if (!queued_next && ctx->opt.profile == 0) (void)prepare_next(ctx); // (a failure only means the next push prepares it itself)
+    if (!queued_next && helper) (void)prepare_next(ctx); // (a failure only means the next push prepares its target itself)
     std::swap(ctx->stream_prev, ctx->stream_cur);         // prev_points_ = curr (slam_node.cpp:128,152), no copy
     ctx->stream_prev_n = n_cur;
     return ICPMI_OK;
@@ -2150,13 +2249,16 @@ void prefetch_worker(FilePrefetch *pf)
             n = size / (4 * (long)sizeof(float)); // file_utils.cpp:127
             if (n > 0 && n <= 700000000) {
                 const size_t bytes = 4 * sizeof(float) * (size_t)n;
-                if (pf->h_cap < bytes) {
-                    if (pf->h_buf) (void)hipHostFree(pf->h_buf);
-                    pf->h_buf = nullptr;
-                    pf->h_cap = 0;
-                    if (hipHostMalloc(&pf->h_buf, bytes + bytes / 4, hipHostMallocDefault) == hipSuccess) pf->h_cap = bytes + bytes / 4;
+                if (pf->h_cap[slot] < bytes) {
+                    // (the copies out of this slot's staging buffer finished long ago: the slot's previous file has been pushed)
+                    if (pf->h_buf[slot]) (void)hipHostFree(pf->h_buf[slot]);
+                    pf->h_buf[slot] = nullptr;
+                    pf->h_cap[slot] = 0;
+                    if (hipHostMalloc(&pf->h_buf[slot], bytes + bytes / 4, hipHostMallocDefault) == hipSuccess) pf->h_cap[slot] = bytes + bytes / 4;
                 }
+                if (!pf->h_runs && hipHostMalloc((void **)&pf->h_runs, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) pf->h_runs = nullptr;
                 if (pf->d_cap[slot] < (size_t)n) {
+                    if (pf->stream) (void)hipStreamSynchronize(pf->stream);
                     if (pf->d_f32[slot]) (void)hipFree(pf->d_f32[slot]);
                     if (pf->d_raw[slot]) (void)hipFree(pf->d_raw[slot]);
                     pf->d_f32[slot] = nullptr;
@@ -2167,15 +2269,17 @@ void prefetch_worker(FilePrefetch *pf)
                         hipMalloc((void **)&pf->d_raw[slot], 3 * sizeof(double) * cap) == hipSuccess)
                         pf->d_cap[slot] = cap;
                 }
-                if (pf->h_cap >= bytes && pf->d_cap[slot] >= (size_t)n) {
+                if (!pf->stream) (void)hipStreamCreateWithFlags(&pf->stream, hipStreamNonBlocking);
+                if (pf->stream && !pf->filled[slot]) (void)hipEventCreateWithFlags(&pf->filled[slot], hipEventDisableTiming);
+                if (pf->h_cap[slot] >= bytes && pf->d_cap[slot] >= (size_t)n && pf->stream && pf->filled[slot] && pf->h_runs) {
                     // the file in two parts, the first one on its way to the device while the second is read; then the
-                    // widening and the filter are queued behind the copies and ONE wait ends the file
-                    char *h = (char *)pf->h_buf;
+                    // widening and the filter are queued behind the copies and an event behind them all: this thread
+                    // waits for nothing of it
+                    char *h = (char *)pf->h_buf[slot];
                     const size_t half = (bytes / 2) / 16 * 16;
                     const size_t got = fread(h, 1, half, f);
                     if (got < half) memset(h + got, 0, bytes - got); // a short read leaves zeros, like the synchronous path
-                    if (!pf->stream) (void)hipStreamCreateWithFlags(&pf->stream, hipStreamNonBlocking);
-                    bool up = pf->stream && hipMemcpyAsync(pf->d_f32[slot], h, half, hipMemcpyHostToDevice, pf->stream) == hipSuccess;
+                    bool up = hipMemcpyAsync(pf->d_f32[slot], h, half, hipMemcpyHostToDevice, pf->stream) == hipSuccess;
                     if (got == half) {
                         const size_t got2 = fread(h + half, 1, bytes - half, f);
                         if (got2 < bytes - half) memset(h + half + got2, 0, bytes - half - got2);
@@ -2187,22 +2291,20 @@ void prefetch_worker(FilePrefetch *pf)
                                            (const float *)pf->d_f32[slot], (int)n, 4, pf->d_raw[slot]);
                         td = now();
                         pf->filtered_voxel[slot] = 0.0;
-                        bool filtered = false;
-                        int64_t nf = 0;
+                        pf->pend_filtered[slot] = false;
                         if (voxel > 0.0 && reserve_raw(pf->filtered[slot], sizeof(double) * 3 * (size_t)n) == hipSuccess) {
                             const VoxelScratch vs{&pf->sc_bbox, &pf->sc_box, &pf->sc_keys, &pf->sc_vals, &pf->sc_tmp, 0};
                             const char *msg = "";
-                            filtered = voxel_filter_core(pf->stream, vs, pf->d_raw[slot], (int)n, voxel, (double *)pf->filtered[slot].p, n, &nf,
-                                                         true, &msg, true) == ICPMI_OK;
-                            // (otherwise the push filters the raw points itself and reports what is wrong with them)
+                            int64_t unused = 0;
+                            pf->h_runs[2 * slot] = 0u;
+                            pf->h_runs[2 * slot + 1] = 1u; // (reads as "could not be keyed" until the filter's own words arrive)
+                            pf->pend_filtered[slot] = voxel_filter_core(pf->stream, vs, pf->d_raw[slot], (int)n, voxel, (double *)pf->filtered[slot].p, n,
+                                                                        &unused, true, &msg, true, pf->h_runs + 2 * slot) == ICPMI_OK;
+                            pf->pend_voxel[slot] = voxel;
+                            // (a filter that could not be queued, or whose outcome says the grid cannot be keyed: the push
+                            // filters the raw points itself and reports what is wrong with them)
                         }
-                        // the points are on the device before the file is announced: the push needs no event
-                        // (a filter that gave up may have returned without waiting)
-                        ok = hipStreamSynchronize(pf->stream) == hipSuccess && hipGetLastError() == hipSuccess;
-                        if (ok && filtered) {
-                            pf->filtered_n[slot] = nf;
-                            pf->filtered_voxel[slot] = voxel;
-                        }
+                        ok = hipEventRecord(pf->filled[slot], pf->stream) == hipSuccess && hipGetLastError() == hipSuccess;
                     }
                 }
             }
@@ -2215,6 +2317,7 @@ void prefetch_worker(FilePrefetch *pf)
             pf->ready[slot] = path;
             pf->ready_n[slot] = n;
             pf->ready_seq[slot] = ++pf->seq;
+            pf->pending[slot] = true; // (the push waits for `filled[slot]`)
         }
         pf->want.clear();
         pf->busy = false;
@@ -2271,6 +2374,25 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
             const int64_t n = pf->ready_n[slot];
             pf->taking = slot; // the worker fills the other one meanwhile
             lk.unlock();
+            if (pf->pending[slot]) {
+                // the worker announced the file with its copies, the widening and the filter still queued: wait for them here,
+                // then look at what the filter left in pinned memory
+                pf->pending[slot] = false;
+                const bool arrived = hipEventSynchronize(pf->filled[slot]) == hipSuccess;
+                if (arrived && pf->pend_filtered[slot] && pf->h_runs[2 * slot + 1] == 0u && (int64_t)pf->h_runs[2 * slot] <= n) {
+                    pf->filtered_n[slot] = (int64_t)pf->h_runs[2 * slot];
+                    pf->filtered_voxel[slot] = pf->pend_voxel[slot];
+                }
+                if (!arrived) { // the slot's contents cannot be trusted: the synchronous path below reads the file itself
+                    (void)hipGetLastError();
+                    lk.lock();
+                    pf->ready[slot].clear();
+                    pf->slot_used[slot] = false;
+                    pf->taking = -1;
+                    lk.unlock();
+                    goto read_it_here;
+                }
+            }
             int rc2;
             if (pf->filtered_voxel[slot] > 0.0 && pf->filtered_voxel[slot] == voxel_size) {
                 // the worker filtered it too: its buffer becomes the current scan (ours goes to the worker in exchange;
@@ -2299,6 +2421,7 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
         }
         // not there (never asked for, or the worker could not read it): the synchronous path reads it and reports
     }
+read_it_here:
     FILE *f = fopen(path, "rb");
     if (!f) return fail(ctx, ICPMI_ERR_ARG, "Cannot open file: %s", path); // file_utils.cpp:116-118
     struct Closer { FILE *f; ~Closer() { fclose(f); } } closer{f};
