@@ -208,6 +208,9 @@ struct icpmi_ctx {
     hipEvent_t prep_done = nullptr;                 // recorded on the helper's stream behind a preparation
     hipEvent_t scan_ready = nullptr;                // recorded on this context's stream behind the filter of the scan to prepare
     bool helper_busy = false;                       // a preparation is queued on the helper and nothing has waited for it yet
+    // where the calling thread's time goes in the frame stream (ICPMI_STREAM_STATS=1: printed when the context is destroyed)
+    double t_push = 0, t_wait_file = 0, t_prep_queue = 0, t_align = 0;
+    long pushes = 0;
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     DevBuf src_sort, blk_lists, work;         // pruned engine: Morton order of the source, per-block split lists, unit list
@@ -1507,6 +1510,10 @@ void icpmi_destroy(icpmi_ctx *ctx)
         delete pf;
         ctx->prefetch = nullptr;
     }
+    if (getenv("ICPMI_STREAM_STATS") && ctx->pushes > 0)
+        fprintf(stderr, "frame stream, calling thread, ms per push over %ld pushes (the first ones carry the allocations): whole push %.4f, of it "
+                        "waiting for the prefetched file %.4f, registration call %.4f (of it queueing the next target's preparation %.4f)\n",
+                ctx->pushes, ctx->t_push / ctx->pushes, ctx->t_wait_file / ctx->pushes, ctx->t_align / ctx->pushes, ctx->t_prep_queue / ctx->pushes);
     if (ctx->prep_helper) icpmi_destroy(ctx->prep_helper);
     ctx->prep_helper = nullptr;
     if (ctx->prep_done) (void)hipEventDestroy(ctx->prep_done);
@@ -2167,6 +2174,8 @@ int stream_register(icpmi_ctx *ctx, int64_t n_cur, int64_t min_points, const icp
     auto prepare_next = [](icpmi_ctx *c) -> int {
         icpmi_ctx *h = c->prep_helper;
         if (!h || c->stream_cur_n <= 0) return ICPMI_OK;
+        struct Clock { icpmi_ctx *c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                       ~Clock() { c->t_prep_queue += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } clock{c};
         if (hipStreamWaitEvent(h->stream, c->scan_ready, 0) != hipSuccess) return ICPMI_ERR_HIP;
         const int r = prepare_target(h, (const double *)c->stream_cur.p, (int)c->stream_cur_n, (int)c->stream_cur_n);
         c->helper_busy = true; // (whatever was queued reads the scan: somebody has to wait for it before the scan's buffer is reused)
@@ -2201,10 +2210,12 @@ int stream_register(icpmi_ctx *ctx, int64_t n_cur, int64_t min_points, const icp
         // search structure and normals are the adopted ones (prepared during the previous push, as a rule)
         info->status = ICPMI_STREAM_REGISTERED;
         queued_next = helper != nullptr;
-        if ((rc = align_device(ctx, (const double *)ctx->stream_cur.p, n_cur, (const double *)ctx->stream_prev.p,
-                               ctx->stream_prev_n, cfg, result, error_history, history_cap, nullptr,
-                               helper ? +prepare_next : nullptr)))
-            return rc;
+        const auto ta = std::chrono::steady_clock::now();
+        rc = align_device(ctx, (const double *)ctx->stream_cur.p, n_cur, (const double *)ctx->stream_prev.p,
+                          ctx->stream_prev_n, cfg, result, error_history, history_cap, nullptr,
+                          helper ? +prepare_next : nullptr);
+        ctx->t_align += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
+        if (rc) return rc;
     }
     if (!queued_next && helper) (void)prepare_next(ctx); // (a failure only means the next push prepares its target itself)
     std::swap(ctx->stream_prev, ctx->stream_cur);         // prev_points_ = curr (slam_node.cpp:128,152), no copy
@@ -2355,6 +2366,8 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
     int rc;
     if ((rc = check_common(ctx))) return rc;
     if (!path) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    struct PushClock { icpmi_ctx *c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                       ~PushClock() { c->t_push += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->pushes += 1; } } push_clock{ctx};
     if (!is_bin(path)) {
         // PLY: host parser (header rules, ASCII numbers), then the host-pointer form
         int64_t n = 0;
@@ -2378,7 +2391,9 @@ int icpmi_stream_push_file(icpmi_ctx *ctx, const char *path, double voxel_size, 
                 // the worker announced the file with its copies, the widening and the filter still queued: wait for them here,
                 // then look at what the filter left in pinned memory
                 pf->pending[slot] = false;
+                const auto tw = std::chrono::steady_clock::now();
                 const bool arrived = hipEventSynchronize(pf->filled[slot]) == hipSuccess;
+                ctx->t_wait_file += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
                 if (arrived && pf->pend_filtered[slot] && pf->h_runs[2 * slot + 1] == 0u && (int64_t)pf->h_runs[2 * slot] <= n) {
                     pf->filtered_n[slot] = (int64_t)pf->h_runs[2 * slot];
                     pf->filtered_voxel[slot] = pf->pend_voxel[slot];
