@@ -15,7 +15,8 @@ def newest(pattern):
 
 for f in ("bench.json", "bench_20.json", "bench_extra.json", "engines_100k.json", "engines_1m.json", "engines_lidar_raw.json",
           "event_overhead.txt", "sequence_200.json", "sequence_200_noprefetch.json", "sequence_200_map.json", "summary.txt", "ab_r1_r2.json", "threshold_sweep.json",
-          "ab_fuse_finish.json", "coarse_clock.json"):
+          "ab_fuse_finish.json", "coarse_clock.json", "ab_small.json", "small_clock.json", "batch_timing.json", "iteration_sensitivity.json",
+          "stream_threads.txt"):
     if os.path.exists(os.path.join(F, f)) and os.path.getsize(os.path.join(F, f)) > 0:
         shutil.copy(os.path.join(F, f), os.path.join(P, f))
 shutil.copy(newest(F + "/stats/**/*kernel_stats.csv"), P + "/kernel_stats.csv")
@@ -44,3 +45,10 @@ print({k: q[k] for k in ("gpu_ms_per_frame_file_to_pose", "gpu_frame_ms_median")
 print(json.dumps(json.load(open(os.path.join(P, "ab_fuse_finish.json")))["summary_min_over_legs"]))
 print(open(os.path.join(P, "coarse_clock.json")).read())
 print(json.dumps(json.load(open(os.path.join(P, "bench_extra.json"))))[:1400])
+print(json.dumps(json.load(open(os.path.join(P, "ab_small.json")))["summary_min_over_legs"]))
+print(open(os.path.join(P, "batch_timing.json")).read())
+print(open(os.path.join(P, "small_clock.json")).read())
+q = json.load(open(os.path.join(P, "iteration_sensitivity.json")))
+print(q["fixtures"], {k: v for k, v in q["stream"].items() if k != "worst"})
+print([(r["theta"], "%.2e" % r["kappa"], r["iterations"]) for r in q["kappa_sweep"]])
+print(open(os.path.join(P, "stream_threads.txt")).read())
