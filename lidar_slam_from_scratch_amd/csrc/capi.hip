@@ -544,7 +544,7 @@ bool coarse_half_units(const icpmi_ctx *ctx, int n, int splits)
 int resolve_blocks(int n)
 {
     const int w = resolve_waves(n);
-    const int per = w > 0 ? 4 * w : (w == -32 ? 128 : 4 * kResolveQ);
+    const int per = w > 0 ? 4 * w : (w == -32 ? kResolveWW * 32 : kResolveWW * kResolveQ);
     return (n + per - 1) / per;
 }
 
@@ -603,8 +603,8 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits, frames,  \
         (const NnFrame *)ctx->nn_misc.p, d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, blk_cnt, blk_list, st
     switch (resolve_waves(n)) {
-    case 0: hipLaunchKernelGGL(k_nn_resolve<16>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
-    case -32: hipLaunchKernelGGL(k_nn_resolve<32>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
+    case 0: hipLaunchKernelGGL(k_nn_resolve<16>, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
+    case -32: hipLaunchKernelGGL(k_nn_resolve<32>, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     case 4: hipLaunchKernelGGL(k_nn_resolve4<4>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     case 8: hipLaunchKernelGGL(k_nn_resolve4<8>, dim3(resolve_blocks(n)), dim3(512), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     default: hipLaunchKernelGGL(k_nn_resolve4<16>, dim3(resolve_blocks(n)), dim3(1024), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
@@ -1137,6 +1137,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     StageTimer *t_loop = new StageTimer(ctx, ST_LOOP);
     struct Closer2 { StageTimer *&p; ~Closer2() { delete p; p = nullptr; } } close_loop{t_loop};
     for (int i = 0; i < kFlagRing; ++i) ctx->h_flags[i] = 0;
+    bool ended_early = false; // the host has SEEN the device leave the loop on a convergence test
     // `after_first` (may be null): called once the first iterations are queued and before the host first waits for
     // the device -- what it queues (on another stream) costs the host its launch time while the device is busy
     bool after_first_done = after_first == nullptr;
@@ -1160,13 +1161,17 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                 if ((spin & 63) == 63) sched_yield();
                 v = *flag;
             }
-            if (v & 1) break; // loop already left on the device
+            if (v & 1) { // loop already left on the device
+                ended_early = true;
+                break;
+            }
         }
         if ((rc = iteration(0, ctx->d_flags + it % kFlagRing, it + 1))) return rc;
     }
-    // post-loop evaluation (icp.hpp:235-252): a full pass after exhaustion, a re-statement
-    // of the last error after a convergence break
-    if ((rc = iteration(1, nullptr, 0))) return rc;
+    // post-loop evaluation (icp.hpp:235-252): a full pass after exhaustion; after a convergence break it restates
+    // the last error, which the step that broke the loop has already entered (step_update): nothing to queue then.
+    // (Single-GPU loops only: in a sharded run `done` is agreed one exchange later, k_step.)
+    if (!(ended_early && !sharded) && (rc = iteration(1, nullptr, 0))) return rc;
     if (!after_first_done) (void)after_first(ctx);
     delete t_loop;
     t_loop = nullptr;

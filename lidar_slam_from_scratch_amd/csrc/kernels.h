@@ -46,6 +46,8 @@ struct IcpState {
     int32_t loops;
     int32_t max_hist;
     int32_t error;          // sharded runs: the ranks disagreed on `done` (k_step)
+    int32_t finalized;      // the post-loop entry (icp.hpp:235-252) is already in the history (see step_update)
+    int32_t pad;
 };
 
 // ------------------------------------------------------------------------------------
@@ -237,13 +239,14 @@ __device__ inline void finish_sums(const double *__restrict__ partials, int nblo
 __device__ inline void step_update(IcpState *st, double *history, int final_pass)
 {
     if (st->done) {
-        if (final_pass) {
+        if (final_pass && !st->finalized) {
             // the loop broke on convergence: the source has not moved since the last
             // evaluation, so the reference's post-loop pass (icp.hpp:235-252) recomputes
             // exactly last_error
             st->final_error = st->last_error;
             if (history && st->hist_len < st->max_hist) history[st->hist_len] = st->last_error;
             st->hist_len += 1;
+            st->finalized = 1;
         }
         return;
     }
@@ -257,14 +260,16 @@ __device__ inline void step_update(IcpState *st, double *history, int final_pass
         return;
     }
     st->loops += 1;
-    if (error < st->min_error) { // icp.hpp:210-213
+    if (error < st->min_error || fabs(st->prev_error - error) < st->tolerance) { // icp.hpp:210-213, 214-217
         st->converged = 1;
         st->done = 1;
-        return;
-    }
-    if (fabs(st->prev_error - error) < st->tolerance) { // icp.hpp:214-217
-        st->converged = 1;
-        st->done = 1;
+        // The post-loop pass of a loop that broke here restates this very error (the source has not moved:
+        // icp.hpp:235-252 on unchanged data).  It is entered into the history NOW, so that a host that has seen the
+        // loop end need not queue a post-loop pass at all.
+        st->final_error = error;
+        if (history && st->hist_len < st->max_hist) history[st->hist_len] = error;
+        st->hist_len += 1;
+        st->finalized = 1;
         return;
     }
     double x[6];

@@ -1213,8 +1213,12 @@ constexpr int kResolveQ = 16;
 // of a query share its bookkeeping.  Q = 32 halves the waves of a pass (C3: 3,125, all resident
 // at once, where the 6,250 of Q = 16 need a second round at 5 waves per SIMD) at the price of a
 // longer chain per wave (8 scan rounds instead of 4).
+#ifndef ICPMI_RESOLVE_WW
+#define ICPMI_RESOLVE_WW 4 /* waves per workgroup = Q * WW queries per partial row of normal-equation terms */
+#endif
+constexpr int kResolveWW = ICPMI_RESOLVE_WW;
 template <int Q>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOLVE_OCC, 8))) void k_nn_resolve(
+__global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOLVE_OCC, 8))) void k_nn_resolve(
     const double *__restrict__ qry, int n,
                                                     const double *__restrict__ sorted,
                                                     const unsigned *__restrict__ perm, int m, int ms,
@@ -1237,7 +1241,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ql = lane & (Q - 1), sub = lane / Q;
     const int l16 = lane & 15, quarter = lane >> 4;
-    const int qbase = (blockIdx.x * 4 + wave) * Q;
+    const int qbase = (blockIdx.x * kResolveWW + wave) * Q;
     // pruned engine: only the splits on the query block's list were evaluated (the queries
     // of a wave share a block); otherwise all of them
     static_assert(kCoarseQueries % Q == 0, "a wave's queries share a coarse block");
@@ -1363,8 +1367,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
     if (partials) {
         // Q rows of 28 terms per wave -> LDS (row stride 29: conflict-free), then lane l sums
         // column l & 31 over the Q / 2 rows of half l >> 5 and the halves meet with one exchange
-        __shared__ double jrow[4][Q][29];
-        __shared__ double red[4][28];
+        __shared__ double jrow[kResolveWW][Q][29];
+        __shared__ double red[kResolveWW][28];
         if (sub == 0) { // each term goes to LDS as it is formed (28 live doubles would cost 2 waves per SIMD)
             double J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, b = 0.0;
             if (valid) {
@@ -1406,7 +1410,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOL
         __syncthreads();
         if (threadIdx.x < 28) {
             const int e = threadIdx.x;
-            partials[(size_t)blockIdx.x * kSumsStride + e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+            double v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+#pragma unroll
+            for (int w = 4; w < kResolveWW; ++w) v += red[w][e];
+            partials[(size_t)blockIdx.x * kSumsStride + e] = v;
         }
     }
 }
