@@ -27,8 +27,19 @@ for f in ("sequence_40.json", "sequence_40_under_rocprof.json"):
     shutil.copy(os.path.join(F, "small", f), os.path.join(P, "small", f))
 t = open(os.path.join(F, "shard_overhead.json")).read()
 open(os.path.join(P, "shard_overhead.json"), "w").write(t[t.index("{"):])      # (RCCL prints its banner on stdout)
-s = open(os.path.join(P, "summary.txt")).read()
-open(os.path.join(P, "summary.txt"), "w").write(re.sub(r"/tmp/code/[^ ]*/repo/", "", s))
+# summary.txt from the files just collected (final_profile.sh's two parts run on different boxes, each box's own
+# summary covers its part only)
+import subprocess, tempfile
+tmp = tempfile.mkdtemp(prefix="icpmi_sum_")
+os.makedirs(tmp + "/main"); os.makedirs(tmp + "/small")
+shutil.copy(P + "/kernel_stats.csv", tmp + "/main/main_kernel_stats.csv")
+shutil.copy(P + "/small/kernel_stats.csv", tmp + "/small/small_kernel_stats.csv")
+for g in ("fetch_size", "write_size", "grbm_gui_active", "sq_insts_valu", "sq_waves"):
+    os.makedirs(tmp + "/pmc_" + g)
+    shutil.copy(P + "/pmc_%s.csv" % g, tmp + "/pmc_%s/x_counter_collection.csv" % g)
+s = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "prof_summary.py"), tmp], stdout=subprocess.PIPE, text=True).stdout
+open(os.path.join(P, "summary.txt"), "w").write(s.replace(tmp + "/", ""))
+shutil.rmtree(tmp, ignore_errors=True)
 d = json.load(open(os.path.join(P, "bench.json")))
 print("bench30", round(d["value"], 1), round(d["steady_state_it_per_s"], 1), d["roofline"]["avg_launch_ms"], round(d["roofline"]["frac"], 4),
       d["roofline"]["traffic"], round(d["speedup_vs_cpu_1thread"], 1), round(d["cpu_baseline"]["value"], 2))
