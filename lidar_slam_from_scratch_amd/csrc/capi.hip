@@ -209,7 +209,7 @@ struct icpmi_ctx {
     hipEvent_t scan_ready = nullptr;                // recorded on this context's stream behind the filter of the scan to prepare
     bool helper_busy = false;                       // a preparation is queued on the helper and nothing has waited for it yet
     // where the calling thread's time goes in the frame stream (ICPMI_STREAM_STATS=1: printed when the context is destroyed)
-    double t_push = 0, t_wait_file = 0, t_prep_queue = 0, t_align = 0;
+    double t_push = 0, t_wait_file = 0, t_prep_queue = 0, t_align = 0, t_gpu_span = 0;
     long pushes = 0;
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
@@ -1519,6 +1519,7 @@ void icpmi_destroy(icpmi_ctx *ctx)
         fprintf(stderr, "frame stream, calling thread, ms per push over %ld pushes (the first ones carry the allocations): whole push %.4f, of it "
                         "waiting for the prefetched file %.4f, registration call %.4f (of it queueing the next target's preparation %.4f)\n",
                 ctx->pushes, ctx->t_push / ctx->pushes, ctx->t_wait_file / ctx->pushes, ctx->t_align / ctx->pushes, ctx->t_prep_queue / ctx->pushes);
+    if (getenv("ICPMI_STREAM_STATS") && ctx->pushes > 0) fprintf(stderr, "  device span of the registration (events on the context's stream): %.4f ms per push\n", ctx->t_gpu_span / ctx->pushes);
     if (ctx->prep_helper) icpmi_destroy(ctx->prep_helper);
     ctx->prep_helper = nullptr;
     if (ctx->prep_done) (void)hipEventDestroy(ctx->prep_done);
@@ -2215,11 +2216,21 @@ int stream_register(icpmi_ctx *ctx, int64_t n_cur, int64_t min_points, const icp
         // search structure and normals are the adopted ones (prepared during the previous push, as a rule)
         info->status = ICPMI_STREAM_REGISTERED;
         queued_next = helper != nullptr;
+        static const bool span = getenv("ICPMI_STREAM_STATS") != nullptr;
+        static hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (span && !e0) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+        if (span) (void)hipEventRecord(e0, ctx->stream);
         const auto ta = std::chrono::steady_clock::now();
         rc = align_device(ctx, (const double *)ctx->stream_cur.p, n_cur, (const double *)ctx->stream_prev.p,
                           ctx->stream_prev_n, cfg, result, error_history, history_cap, nullptr,
                           helper ? +prepare_next : nullptr);
         ctx->t_align += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
+        if (span) {
+            (void)hipEventRecord(e1, ctx->stream);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ctx->t_gpu_span += ms;
+        }
         if (rc) return rc;
     }
     if (!queued_next && helper) (void)prepare_next(ctx); // (a failure only means the next push prepares its target itself)

@@ -85,3 +85,55 @@ def test_sharded_icp_world2_gloo(tmp_path, oracle):
     dt, dr = synth.pose_delta(r[0]["T"], ref.transformation)
     assert dt < 1e-10 and dr < 1e-10               # only the summation order differs
     np.testing.assert_allclose(r[0]["hist"], ref.error_history[:-1], atol=1e-12)
+
+
+def test_local_group_exchanges_are_rank_ordered_and_identical():
+    """dist.LocalGroup (N ranks as N threads of one process: what the C4 rehearsal on one GPU runs on): the all-reduce
+    adds the ranks' vectors in rank order on every rank (identical bits everywhere, the property the sharded path
+    needs of any transport), the all-gather leaves every rank's slice at its rank's offset.  Driven here by a stand-in
+    for the context: an object whose comm_init_callbacks keeps the two callbacks."""
+    from lidar_slam_from_scratch_amd import dist as icpdist
+
+    class FakeCtx:
+        def comm_init_callbacks(self, n_ranks, rank, allreduce, allgather):
+            self.n_ranks, self.rank, self.allreduce, self.allgather = n_ranks, rank, allreduce, allgather
+
+    world = 8
+    group = icpdist.LocalGroup(world, timeout_s=30.0)
+    rng = np.random.default_rng(3)
+    vecs = rng.normal(0, 1, (world, 30)) * 10.0 ** rng.integers(-8, 9, (world, 1))     # sums whose order matters
+
+    def body(rank):
+        ctx = FakeCtx()
+        group.attach(ctx, rank)
+        out = []
+        for rep in range(3):
+            buf = vecs[rank].copy() * (rep + 1)
+            ctx.allreduce(buf)
+            out.append(buf)
+        gat = np.zeros(world * 5)
+        gat[rank * 5:(rank + 1) * 5] = rank + 0.25
+        ctx.allgather(gat, 5)
+        return out, gat
+
+    res = group.run(body)
+    for rep in range(3):
+        want = vecs[0].copy() * (rep + 1)
+        for r in range(1, world):
+            want = want + vecs[r] * (rep + 1)                         # rank order, left to right
+        for rank in range(world):
+            assert (res[rank][0][rep] == want).all()
+    for rank in range(world):
+        assert (res[rank][1] == np.repeat(np.arange(world) + 0.25, 5)).all()
+    assert group.allreduces == 3
+
+    def failing(rank):                                               # a rank that dies must not leave the others waiting
+        ctx = FakeCtx()
+        group2.attach(ctx, rank)
+        if rank == 3:
+            raise RuntimeError("rank 3 gives up")
+        ctx.allreduce(np.zeros(4))
+
+    group2 = icpdist.LocalGroup(world, timeout_s=30.0)
+    with pytest.raises(Exception):
+        group2.run(failing)
