@@ -32,6 +32,7 @@
 #include "kernels.h"
 #include "nn_mfma.h"
 #include "icp_small.h"
+#include "knn_lists.h"
 #include "voxel.h"
 #include "scan_context.h"
 #include "occupancy.h"
@@ -647,6 +648,22 @@ int reduce_blocks(const icpmi_ctx *ctx, int n)
     return std::max(1, std::min(ctx->cu_count, (n + 255) / 256));
 }
 
+// Normal estimation takes the target's rows in Morton order (a rank's slice is then a range of sorted positions) with
+// the pruned engine, whose blocks must be compact, and with the all-pairs engine's list form (knn_lists.h;
+// ICPMI_KNN_LISTS=0: round 2's slot-minimum form, rows in point order)
+bool knn_lists_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("ICPMI_KNN_LISTS");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+bool sorted_normal_rows(const icpmi_ctx *ctx, int k, int m)
+{
+    return ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && (ctx->nn_pruned || knn_lists_enabled()) && k <= 32 && m >= mfma_min_targets();
+}
+
 #ifndef ICPMI_KNN_CHUNK_DEFAULT_MB
 #define ICPMI_KNN_CHUNK_DEFAULT_MB 1024
 #endif
@@ -685,10 +702,13 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
             }
             return (long)ICPMI_KNN_CHUNK_DEFAULT_MB << 20;
         }();
-        const long budget = by_sorted_row ? (4l << 30) : knn_budget;
-        long chunk = (budget / ((long)nslots * 2)) / kCoarseQueries * kCoarseQueries; // 2 bytes per slot minimum (bf16)
+        // all-pairs engine, rows in the target's Morton order: bound first, lists instead of minima (knn_lists.h)
+        const bool lists = by_sorted_row && !ctx->nn_pruned;
+        constexpr long kListRowBytes = sizeof(double) + sizeof(float) + sizeof(int) + sizeof(unsigned) * kKnnEntCap;
+        const long budget = lists ? (1l << 30) : by_sorted_row ? (4l << 30) : knn_budget;
+        long chunk = (budget / (lists ? kListRowBytes : (long)nslots * 2)) / kCoarseQueries * kCoarseQueries; // 2 bytes per slot minimum (bf16)
         chunk = std::max<long>(kCoarseQueries, std::min<long>(chunk, ((long)rows + kCoarseQueries - 1) / kCoarseQueries * kCoarseQueries));
-        if ((rc = reserve(ctx, ctx->slotmin, sizeof(unsigned short) * (size_t)chunk * nslots))) return rc;
+        if ((rc = reserve(ctx, ctx->slotmin, lists ? (size_t)kListRowBytes * chunk : sizeof(unsigned short) * (size_t)chunk * nslots))) return rc;
         if ((rc = reserve(ctx, ctx->fb_list, sizeof(int) * ((size_t)rows + 16)))) return rc;
         int *fb_count = (int *)ctx->fb_list.p, *fb_list = fb_count + 16;
         HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, sizeof(int), s));
@@ -697,7 +717,7 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
         const int cblocks = (int)(chunk / kCoarseQueries);
         int *blk_cnt = nullptr, *blk_list = nullptr;
         unsigned *work = nullptr, *work_cnt = nullptr;
-        if (by_sorted_row) {
+        if (by_sorted_row && !lists) {
             if ((rc = reserve(ctx, ctx->blk_lists, sizeof(int) * (size_t)cblocks * ((size_t)splits + 1)))) return rc;
             if ((rc = reserve(ctx, ctx->work, sizeof(unsigned) * (size_t)cblocks * (size_t)splits))) return rc;
             blk_cnt = (int *)ctx->blk_lists.p;
@@ -708,7 +728,24 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
         for (long c0 = row0; c0 < row1; c0 += chunk) {
             const int nq = (int)std::min<long>(chunk, row1 - c0);
             const int nblk = (nq + kCoarseQueries - 1) / kCoarseQueries;
-            if (by_sorted_row) {
+            if (lists) {
+                double *t_row = (double *)ctx->slotmin.p;
+                float *thr_row = (float *)(t_row + chunk);
+                int *cnt_row = (int *)(thr_row + chunk);
+                unsigned *ent_row = (unsigned *)(cnt_row + chunk);
+                const KnnLists kl{thr_row, cnt_row, ent_row};
+                hipLaunchKernelGGL(k_knn_prebound, dim3((nq + 3) / 4), dim3(256), 0, s, sorted, m, ctx->nn_ms, k, (int)c0, nq,
+                                   (const NnFrame *)ctx->nn_misc.p, t_row, thr_row, cnt_row);
+                if (coarse_half_units(ctx, nq, splits)) {
+                    constexpr int per = kCoarseQueries / kCoarseQT;
+                    hipLaunchKernelGGL((k_nn_coarse_rows<1, kCoarseWaves>), dim3((nq + per - 1) / per, splits), dim3(kCoarseThreads), 0,
+                                       s, sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, kl);
+                } else
+                    hipLaunchKernelGGL((k_nn_coarse_rows<kCoarseQT, kCoarseWaves>), dim3(nblk, splits), dim3(kCoarseThreads), 0, s,
+                                       sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, kl);
+                hipLaunchKernelGGL(k_knn_resolve_lists, dim3((nq + 3) / 4), dim3(256), 0, s, sorted, perm, m, ctx->nn_ms, k, (int)c0,
+                                   nq, (const double *)t_row, (const int *)cnt_row, (const unsigned *)ent_row, knn, fb_list, fb_count);
+            } else if (by_sorted_row) {
                 HIP_TRY(ctx, hipMemsetAsync(work_cnt, 0, sizeof(unsigned), s));
                 hipLaunchKernelGGL(k_knn_block_bounds, dim3(nblk), dim3(kCoarseQueries), 0, s, sorted, m, ctx->nn_ms, (int)c0, nq,
                                    std::min(k, 64), frames, splits, blk_cnt, blk_list, work, work_cnt);
@@ -905,8 +942,7 @@ int prepare_target(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     int rc;
     if ((rc = reserve(ctx, ctx->nrm, sizeof(double) * 3 * (size_t)m))) return rc;
     if ((rc = prepare_nn(ctx, d_tgt, m, n_hint))) return rc;
-    const bool sorted_rows = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && ctx->nn_pruned && ctx->opt.normal_k <= 32 &&
-                             m >= mfma_min_targets();
+    const bool sorted_rows = sorted_normal_rows(ctx, ctx->opt.normal_k, m);
     if ((rc = launch_normals(ctx, d_tgt, m, ctx->opt.normal_k, 0, m, (double *)ctx->nrm.p, sorted_rows, true))) return rc;
     if ((rc = sort_normals(ctx, m))) return rc;
     ctx->prep_tgt = d_tgt;
@@ -960,7 +996,9 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     const bool sharded_run = ctx->comm != nullptr || ctx->cb_allreduce != nullptr;
     const bool prepared = !sharded_run && ctx->prep_valid && ctx->prep_tgt == d_tgt && ctx->prep_m == m &&
                           ctx->prep_engine == engine_for(ctx, m, n);
-    if (!prepared && (rc = prepare_nn(ctx, d_tgt, m, n))) return rc;
+    // (the ranks of a sharded run must agree on the engine -- it decides the order of the normal rows they gather -- so
+    // there AUTO looks at the target alone, whatever this rank's share of the source)
+    if (!prepared && (rc = prepare_nn(ctx, d_tgt, m, sharded_run ? std::max(n, kMfmaMinQueries) : n))) return rc;
     // with the MFMA engine the resolve kernel also forms the normal-equation partial sums
     const bool fused = ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16;
     // small clouds: one kernel per iteration for the rows' work (icp_small.h), then k_finish_step
@@ -974,7 +1012,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     const bool sharded = ctx->comm != nullptr || ctx->cb_allreduce != nullptr; // exchanges on, even for 1 rank
     // pruned engine: rows are taken in the target's Morton order, so that a block's neighbours
     // lie in few splits (launch_normals); a rank's slice is then a range of sorted positions
-    const bool sorted_rows = fused && ctx->nn_pruned && ctx->opt.normal_k <= 32 && m >= mfma_min_targets();
+    const bool sorted_rows = sorted_normal_rows(ctx, ctx->opt.normal_k, m);
     if (sharded) {
         int per = (m + ctx->n_ranks - 1) / ctx->n_ranks;
         if (sorted_rows) per = (per + kCoarseQueries - 1) / kCoarseQueries * kCoarseQueries; // whole blocks (and slots) per rank
@@ -1700,7 +1738,7 @@ int icpmi_estimate_normals(icpmi_ctx *ctx, const double *points_xyz, int64_t n, 
     hipStream_t s = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_c.p, points_xyz, sizeof(double) * 3 * (size_t)m, hipMemcpyHostToDevice, s));
     if ((rc = prepare_nn(ctx, (const double *)ctx->stage_c.p, m, m))) return rc;
-    const bool sorted_rows = ctx->nn_pruned && ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && k <= 32 && m >= mfma_min_targets();
+    const bool sorted_rows = sorted_normal_rows(ctx, k, m);
     if ((rc = launch_normals(ctx, (const double *)ctx->stage_c.p, m, k, 0, m, (double *)ctx->nrm.p, sorted_rows, true))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(normals_xyz, ctx->nrm.p, sizeof(double) * 3 * (size_t)m, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));

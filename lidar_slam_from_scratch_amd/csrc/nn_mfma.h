@@ -429,11 +429,22 @@ __device__ __forceinline__ float tag_low5(float x, unsigned tag)
 
 // MODE 0: 1-NN epilogue -> coarse[split][n] = (tagged min, second min over the 32 columns)
 // MODE 1: k-NN epilogue  -> slotmin[query][split*32 + column], every column minimum kept (bf16, rounded down)
+// MODE 2: k-NN epilogue for rows that come with a bound (knn_lists.h): the columns whose minimum is <= the
+//         row's threshold are LISTED per row, 16 columns to a word; nothing else is written
 // QT = 32-query tiles per wave (even); WAVES = waves per workgroup.  (Tried and dropped, see
 // scripts/micro/README.md: issuing a tile's min3 one tile behind its MFMAs, keeping the next B chunk
 // in flight in registers, QT = 4: none beat this form, all cost occupancy.)
 //
 // The three parts of a wave's work on 32*QT queries against one split, shared by the kernels below.
+
+// MODE 2's output: per row a count and up to kKnnEntCap words (split << 17 | half << 16 | mask of the 16 columns
+// split*32 + half*16 + bit whose minimum is under thr[row]); rows are numbered from the launch's first row.
+constexpr int kKnnEntCap = 32;
+struct KnnLists {
+    const float *thr; // [rows] bound on the coarse value of anything the row needs to look at
+    int *cnt;         // [rows] words appended (may exceed kKnnEntCap: the row then goes to the exact kernel)
+    unsigned *ent;    // [rows][kKnnEntCap]
+};
 
 // A operands.  Each lane builds the 16-slot bf16 row of ONE query (lane-per-query: coalesced fp64
 // loads, pieces computed once), rows go through `rows` (64 rows x 32 B of LDS private to the
@@ -509,11 +520,14 @@ __device__ __forceinline__ void coarse_tiles(const uint4 *tiles, const int lane,
 template <int MODE, int QT>
 __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const int q0, const int s, const int nsplits,
                                                 const int n, const f32x16 (&m)[QT], const float (&pn)[(QT + 1) / 2],
-                                                float2 *__restrict__ coarse, float *__restrict__ slotmin)
+                                                float2 *__restrict__ coarse, float *__restrict__ slotmin,
+                                                const KnnLists &kl)
 {
     const int ql = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
+        float thr_q = 0.f;
+        if (MODE == 2) thr_q = kl.thr[q0 + t * 32 + ql < n ? q0 + t * 32 + ql : n - 1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + ql] = m[t][r];
         __builtin_amdgcn_wave_barrier();
@@ -532,7 +546,25 @@ __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const
         }
         __builtin_amdgcn_wave_barrier();
         const int iq = q0 + t * 32 + ql;
-        if (MODE == 1) {
+        if (MODE == 2) {
+            // Nearly every (row, split) pair has nothing under the row's bound: one minimum over the lane's 16
+            // columns, one compare, one ballot.  (+Inf / NaN of a far-away or NaN row become kBig like in MODE 1;
+            // such a row's bound is FLT_MAX, so it lists everything and is handed to the exact kernel.)
+            float mn = min3f(v[0], v[1], v[2]);
+#pragma unroll
+            for (int c = 3; c < 15; c += 2) mn = min3f(mn, v[c], v[c + 1]);
+            mn = min_raw(mn, v[15]);
+            const bool pass = iq < n && min_raw(mn + pnq, kBig) <= thr_q;
+            if (__ballot(pass) != 0ull) {
+                if (pass) {
+                    unsigned mask = 0u;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) mask |= min_raw(v[c] + pnq, kBig) <= thr_q ? (1u << c) : 0u;
+                    const int pos = atomicAdd(kl.cnt + iq, 1);
+                    if (pos < kKnnEntCap) kl.ent[(size_t)iq * kKnnEntCap + pos] = ((unsigned)s << 17) | ((unsigned)half << 16) | mask;
+                }
+            }
+        } else if (MODE == 1) {
             if (iq < n) {
                 // stored as bf16 ROUNDED DOWN (the upper half of the fp32 word of a non-negative value):
                 // half the bytes of the one buffer that grows with rows x slots; a stored minimum never
@@ -588,7 +620,8 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
                                             const double *__restrict__ qry, const int n, const size_t qstride,
                                             const uint4 *__restrict__ Bpack,
                                             const SplitFrame *__restrict__ frames,
-                                            float2 *__restrict__ coarse, float *__restrict__ slotmin)
+                                            float2 *__restrict__ coarse, float *__restrict__ slotmin,
+                                            const KnnLists kl = KnnLists{nullptr, nullptr, nullptr})
 {
     constexpr int THREADS = 64 * WAVES;
     constexpr int CHUNK16 = kChunkTiles * 64;  // uint4 per staged chunk (32 KiB)
@@ -636,7 +669,7 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
 
     __syncthreads(); // every wave is done with the B operands
     coarse_epilogue<MODE, QT>(reinterpret_cast<float *>(lds) + wave * (32 * 36), lane, q0, s, nsplits, n, m, pn, coarse,
-                              slotmin);
+                              slotmin, kl);
 #ifdef ICPMI_COARSE_CLOCKS
     if (MODE == 0 && slotmin && threadIdx.x == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(slotmin) + 4 * ((size_t)bx * nsplits + s);
@@ -665,6 +698,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse(
     if (st && st->done) return;
     __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
     coarse_unit<MODE, QT, WAVES>(lds, blockIdx.x, blockIdx.y, gridDim.y, qry, n, 0, Bpack, frames, coarse, slotmin);
+}
+
+// all pairs, rows = `n` consecutive positions of the Morton-sorted target itself (SoA, component stride
+// `qstride`), MODE 2: the k-NN pass of normal estimation (knn_lists.h)
+template <int QT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_nn_coarse_rows(
+    const double *__restrict__ rows, int n, size_t qstride, const uint4 *__restrict__ Bpack,
+    const SplitFrame *__restrict__ frames, KnnLists kl)
+{
+    __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
+    coarse_unit<2, QT, WAVES, true>(lds, blockIdx.x, blockIdx.y, gridDim.y, rows, n, qstride, Bpack, frames, nullptr, nullptr, kl);
 }
 
 // (Measured and not kept, scripts/micro/README.md: a RESIDENT form -- one 16-wave workgroup per CU stages a
@@ -1642,6 +1686,44 @@ __device__ __forceinline__ T wave_sort_asc(T v, int lane)
     return v;
 }
 
+// Rank a wave's `total` candidates (distance cd[], original index cj[], in LDS) by (distance, original index);
+// the k smallest go to out[0..k) closest first -- the order kdtree.hpp:72-76 returns and icp.hpp:41-51 sums in.
+// Fast pass: count strictly smaller distances only (one compare per pair).  Without equal
+// distances that count IS the rank; candidates with equal distance get the same count,
+// which the owner table exposes -- then the full (distance, index) order is evaluated.
+__device__ __forceinline__ void knn_rank_write(const double *cd, const int *cj, int *cr, int *own, const int total,
+                                               const int k, const int lane, int *__restrict__ out)
+{
+    bool clash = false;
+    for (int e = lane; e < total; e += 64) {
+        const double d = cd[e];
+        int r = 0;
+        for (int f = 0; f < total; ++f) r += cd[f] < d ? 1 : 0;
+        cr[e] = r;
+        own[r] = e;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < total; e += 64) clash |= own[cr[e]] != e;
+    if (__ballot(clash) == 0ull) {
+        for (int e = lane; e < total; e += 64) {
+            const int r = cr[e];
+            if (r < k) out[r] = cj[e];
+        }
+        return;
+    }
+    for (int e = lane; e < total; e += 64) {
+        const double d = cd[e];
+        const int j = cj[e];
+        int r = 0;
+        for (int f = 0; f < total; ++f) {
+            const double df = cd[f];
+            const int jf = cj[f];
+            r += (df < d || (df == d && jf < j)) ? 1 : 0;
+        }
+        if (r < k) out[r] = j;
+    }
+}
+
 // LISTED (pruned engine): the rows are SORTED positions row0.. of the target itself, only the
 // splits on the row's block list (k_knn_block_bounds) were evaluated, and the neighbour lists
 // are stored by sorted position.  Slots are then numbered locally, 32 per list entry.
@@ -1978,38 +2060,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve(const double *__restrict__ 
         return;
     }
     __builtin_amdgcn_wave_barrier();
-    // Rank the candidates by (distance, original index); the k smallest go out closest first.
-    // Fast pass: count strictly smaller distances only (one compare per pair).  Without equal
-    // distances that count IS the rank; candidates with equal distance get the same count,
-    // which the owner table exposes -- then the full (distance, index) order is evaluated.
-    bool clash = false;
-    for (int e = lane; e < total; e += 64) {
-        const double d = cand_d[wave][e];
-        int r = 0;
-        for (int f = 0; f < total; ++f) r += cand_d[wave][f] < d ? 1 : 0;
-        cand_r[wave][e] = r;
-        owner[wave][r] = e;
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < total; e += 64) clash |= owner[wave][cand_r[wave][e]] != e;
-    if (__ballot(clash) == 0ull) {
-        for (int e = lane; e < total; e += 64) {
-            const int r = cand_r[wave][e];
-            if (r < k) knn_idx[(size_t)i * k + r] = cand_j[wave][e];
-        }
-        return;
-    }
-    for (int e = lane; e < total; e += 64) {
-        const double d = cand_d[wave][e];
-        const int j = cand_j[wave][e];
-        int r = 0;
-        for (int f = 0; f < total; ++f) {
-            const double df = cand_d[wave][f];
-            const int jf = cand_j[wave][f];
-            r += (df < d || (df == d && jf < j)) ? 1 : 0;
-        }
-        if (r < k) knn_idx[(size_t)i * k + r] = j;
-    }
+    knn_rank_write(cand_d[wave], cand_j[wave], cand_r[wave], owner[wave], total, k, lane, knn_idx + (size_t)i * k);
 }
 
 // out[perm[i]] = in[i], rows of 3 doubles (normals gathered in sorted order -> point order)
