@@ -734,7 +734,7 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                 int *cnt_row = (int *)(thr_row + chunk);
                 unsigned *ent_row = (unsigned *)(cnt_row + chunk);
                 const KnnLists kl{thr_row, cnt_row, ent_row};
-                hipLaunchKernelGGL(k_knn_prebound, dim3((nq + 3) / 4), dim3(256), 0, s, sorted, m, ctx->nn_ms, k, (int)c0, nq,
+                hipLaunchKernelGGL(k_knn_prebound, dim3((nq + kPreRows - 1) / kPreRows), dim3(256), 0, s, sorted, m, ctx->nn_ms, k, (int)c0, nq,
                                    (const NnFrame *)ctx->nn_misc.p, t_row, thr_row, cnt_row);
                 if (coarse_half_units(ctx, nq, splits)) {
                     constexpr int per = kCoarseQueries / kCoarseQT;
@@ -771,7 +771,7 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                                    fb_list, fb_count, (const int *)nullptr, (const int *)nullptr);
             }
         }
-        hipLaunchKernelGGL(k_knn_exact_rows, dim3(1024), dim3(256), (size_t)k * 256 * (sizeof(double) + sizeof(int)),
+        hipLaunchKernelGGL(k_knn_exact_rows, dim3(lists ? ctx->cu_count : 1024), dim3(256), (size_t)k * 256 * (sizeof(double) + sizeof(int)),
                            s, d_pts, m, k, (const int *)fb_list, (const int *)fb_count, knn,
                            by_sorted_row ? perm : (const unsigned *)nullptr, qsep);
         if (ctx->opt.profile) { // visibility only: how many rows took the exact path

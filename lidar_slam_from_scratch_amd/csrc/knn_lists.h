@@ -6,7 +6,7 @@
 // rows in chunks from 300k targets) and found the bound from them afterwards; its resolve was ~1,400
 // instructions per row, most of them loading, bounding and filtering those minima.  Here the rows are
 // taken in the target's MORTON order, where a row's neighbours in the array are neighbours in space:
-//   k_knn_prebound      T(row) = the k-th smallest of 64 disjoint groups of exact distances to the 256 sorted
+//   k_knn_prebound      T(row) = the k-th smallest of 32 disjoint groups of exact distances to the 256 sorted
 //                       positions around the row: k different targets within T, hence d_k <= T; and
 //                       thr(row) = the bound on the coarse value of any target within T that holds for EVERY
 //                       split (all_splits_tau, nn_mfma.h)
@@ -28,39 +28,81 @@ namespace icpmi {
 constexpr int kKnnSlotCap = 192; // listed slots scanned per row
 constexpr int kKnnWindow = 256;  // sorted positions around a row that bound its k-th neighbour
 
-// rows = sorted positions row0 .. row0 + nrows; outputs indexed from the launch's first row
+// Ascending bitonic sort of one value per lane within each HALF of the wave (15 compare-exchange steps).
+__device__ __forceinline__ float half_sort_asc(float v, int hl)
+{
+#pragma unroll
+    for (int k = 2; k <= 32; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const float o = __shfl_xor(v, j, 64);
+            const bool up = (hl & k) == 0, lower = (hl & j) == 0;
+            const float mn = o < v ? o : v, mx = o < v ? v : o;
+            v = (lower == up) ? mn : mx;
+        }
+    }
+    return v;
+}
+
+// rows = sorted positions row0 .. row0 + nrows; outputs indexed from the launch's first row.  A workgroup takes 64
+// consecutive rows: their windows overlap almost entirely, so the union (at most 320 positions) is staged in LDS once
+// -- as one load per (row, position) the kernel pulled 600 MB through the L2 per 100k rows.  One row per HALF-wave
+// (k <= 32): lane l of a half takes positions w0 + l + 32 c -- different targets in different lanes -- and the k-th
+// smallest of the 32 lane minima comes out of a 15-step sort shared by two rows; the coarse-value bounds of the 64
+// rows are formed at the end, one row per lane.
+constexpr int kPreRows = 64;
 __global__ __launch_bounds__(256) void k_knn_prebound(const double *__restrict__ sorted, int m, int ms, int k, int row0,
                                                       int nrows, const NnFrame *__restrict__ gframe,
                                                       double *__restrict__ t_row, float *__restrict__ thr_row,
                                                       int *__restrict__ cnt_row)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int local = blockIdx.x * 4 + wave;
-    if (local >= nrows) return; // wave-uniform
-    const int r = row0 + local;
-    const double px = ICPMI_SX(sorted, ms, r), py = ICPMI_SY(sorted, ms, r), pz = ICPMI_SZ(sorted, ms, r);
-    int w0 = r - kKnnWindow / 2;
-    w0 = w0 + kKnnWindow > m ? m - kKnnWindow : w0;
-    w0 = w0 < 0 ? 0 : w0;
-    const double kInf = 1.7976931348623157e308;
-    double lbest = kInf;
-#pragma unroll
-    for (int c = 0; c < kKnnWindow / 64; ++c) { // lane l: positions w0 + l + 64 c -- different targets in different lanes
-        const int j = w0 + 64 * c + lane;
-        const int jc = j < m ? j : m - 1;
-        const double d = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), px, py, pz);
-        lbest = (j < m && d < lbest) ? d : lbest; // (a NaN distance never enters)
+    __shared__ double wx[kPreRows + kKnnWindow], wy[kPreRows + kKnnWindow], wz[kPreRows + kKnnWindow];
+    __shared__ double tl[kPreRows];
+    const int lane = threadIdx.x & 63, hl = lane & 31, wave = threadIdx.x >> 6;
+    const int first = row0 + blockIdx.x * kPreRows;                 // the workgroup's first row (sorted position)
+    const int last = min(first + kPreRows, row0 + nrows) - 1;       // ... and its last
+    auto window = [&](int r) -> int { // first position of row r's window
+        int w0 = r - kKnnWindow / 2;
+        w0 = w0 + kKnnWindow > m ? m - kKnnWindow : w0;
+        return w0 < 0 ? 0 : w0;
+    };
+    const int lo = window(first), hi = min(window(last) + kKnnWindow, m); // (monotone in r: the union is [lo, hi))
+    for (int t = threadIdx.x; t < hi - lo; t += 256) {
+        wx[t] = ICPMI_SX(sorted, ms, lo + t);
+        wy[t] = ICPMI_SY(sorted, ms, lo + t);
+        wz[t] = ICPMI_SZ(sorted, ms, lo + t);
     }
-    // k-th smallest of the 64 lane minima, as fp32 rounded UP (an upper bound stays one)
-    float lbf = (float)lbest;
-    lbf = (double)lbf < lbest ? __uint_as_float(__float_as_uint(lbf) + 1u) : lbf;
-    const int kk = k < 64 ? k : 64;
-    const double T = (double)__shfl(wave_sort_asc(lbf, lane), kk - 1, 64);
-    if (lane == 0) {
+    __syncthreads();
+    const double kInf = 1.7976931348623157e308;
+    const int kk = k < 32 ? k : 32;
+#pragma unroll 1
+    for (int it = 0; it < kPreRows / 8; ++it) {
+        const int rl = wave * (kPreRows / 4) + it * 2 + (lane >> 5); // row within the workgroup
+        const int r = first + rl <= last ? first + rl : last;
+        const double px = wx[r - lo], py = wy[r - lo], pz = wz[r - lo]; // (a row lies inside its own window)
+        const int off = window(r) - lo + hl;
+        double lbest = kInf;
+#pragma unroll
+        for (int c = 0; c < kKnnWindow / 32; ++c) {
+            const int j = off + 32 * c;
+            const bool in = lo + j < hi; // (only a target of fewer than 256 points has a shorter window)
+            const double d = sqdist(wx[in ? j : 0], wy[in ? j : 0], wz[in ? j : 0], px, py, pz);
+            lbest = (in && d < lbest) ? d : lbest; // (a NaN distance never enters)
+        }
+        // k-th smallest of the 32 lane minima, as fp32 rounded UP (an upper bound stays one)
+        float lbf = (float)lbest;
+        lbf = (double)lbf < lbest ? __uint_as_float(__float_as_uint(lbf) + 1u) : lbf;
+        const float tk = __shfl(half_sort_asc(lbf, hl), (lane & 32) + kk - 1, 64);
+        if (hl == 0) tl[rl] = (double)tk;
+    }
+    __syncthreads();
+    if (threadIdx.x < kPreRows && first + (int)threadIdx.x <= last) {
+        const int r = first + threadIdx.x, local = r - row0;
+        const double T = tl[threadIdx.x];
         // fewer than k finite lane minima (tiny or mostly non-finite targets, a NaN row): everything is listed
         const bool open = !(T < 1.0e299);
         t_row[local] = open ? __builtin_inf() : T;
-        thr_row[local] = open ? 3.4028235e38f : all_splits_tau(px, py, pz, *gframe, T, sqrt(T));
+        thr_row[local] = open ? 3.4028235e38f : all_splits_tau(wx[r - lo], wy[r - lo], wz[r - lo], *gframe, T, sqrt(T));
         cnt_row[local] = 0;
     }
 }
@@ -76,60 +118,61 @@ __global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restr
     __shared__ double cand_d[4][kKnnCap];
     __shared__ int cand_j[4][kKnnCap];
     __shared__ int cand_r[4][kKnnCap], owner[4][kKnnCap];
-    __shared__ int flist[4][kKnnSlotCap];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int local = blockIdx.x * 4 + wave;
-    if (local >= nrows) return; // wave-uniform
+    const int local = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); // scalar: the row's words are read by scalar loads
+    if (local >= nrows) return;
     const int i = row0 + local;
     const int cnt = cnt_row[local];
     double T = t_row[local];
     const unsigned e = lane < cnt && lane < kKnnEntCap ? ent_row[(size_t)local * kKnnEntCap + lane] : 0u;
     const double px = ICPMI_SX(sorted, ms, i), py = ICPMI_SY(sorted, ms, i), pz = ICPMI_SZ(sorted, ms, i);
-    // the listed slots, one word's columns after the other (any order: the ranking below is exact)
-    unsigned mask = e & 0xFFFFu;
-    const int mine = __popc(mask);
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < kKnnEntCap; off <<= 1) {
-        const int o = __shfl_up(incl, off, 64);
-        incl += lane >= off ? o : 0;
-    }
-    const int nf = __shfl(incl, kKnnEntCap - 1, 64);
+    // The listed slots are walked word by word, bit by bit, with SCALAR instructions (a word is read out of its lane;
+    // which slot comes next is the same for the whole wave).  Any order: the ranking below is exact.
+    int nf = 0;
+    for (int w = 0; w < cnt && w < kKnnEntCap; ++w) nf += __popc((unsigned)__builtin_amdgcn_readlane((int)e, w) & 0xFFFFu);
     // no word at all (a sane row lists its own slot: NaN coordinates), more words or slots than fit: exact kernel
     if (cnt <= 0 || cnt > kKnnEntCap || nf > kKnnSlotCap) {
         if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = i;
         return;
     }
-    {
-        int pos = incl - mine;
-        const int base = (int)(e >> 17) * kCols + (int)((e >> 16) & 1u) * 16;
-        while (mask) {
-            flist[wave][pos++] = base + __ffs((int)mask) - 1;
-            mask &= mask - 1u;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
     const int kk = k < 64 ? k : 64;
     const double kInf = 1.7976931348623157e308;
     int total = 0;
     for (int attempt = 0; attempt < 4; ++attempt) {
         total = 0;
+        int w = 0, base = 0;
+        unsigned msk = 0u;
+        auto next_slot = [&]() -> int { // -1: none left
+            while (msk == 0u && w < cnt) {
+                const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)e, w++);
+                msk = word & 0xFFFFu;
+                base = (int)(word >> 17) * kCols + (int)((word >> 16) & 1u) * 16;
+            }
+            if (msk == 0u) return -1;
+            const int b = __ffs((int)msk) - 1;
+            msk &= msk - 1u;
+            return base + b;
+        };
 #pragma unroll 1
-        for (int f0 = 0; f0 < nf && total <= kKnnCap; f0 += kKnnBatch) {
+        while (total <= kKnnCap) {
             constexpr int kRuns = kSlotTargets / 64;
+            int se[kKnnBatch];
+#pragma unroll
+            for (int q = 0; q < kKnnBatch; ++q) se[q] = next_slot();
+            if (se[0] < 0) break;
             double d[kKnnBatch][kRuns];
             int jj[kKnnBatch][kRuns];
 #pragma unroll
             for (int q = 0; q < kKnnBatch; ++q) {
-                const int f = f0 + q;
-                const int se = flist[wave][f < nf ? f : nf - 1];
-                const int j0 = (se / kCols) * kSplitTargets + (se % kCols) * kSlotTargets;
+                const int sq = se[q] < 0 ? se[0] : se[q];
+                const int j0 = (sq / kCols) * kSplitTargets + (sq % kCols) * kSlotTargets;
 #pragma unroll
                 for (int o = 0; o < kRuns; ++o) {
+                    // (no clamp: a slot's 64 positions lie inside the array's stride `ms`, m rounded up to 64 -- whatever
+                    // the padding holds is dropped below -- so the addresses are a scalar base + the lane)
                     jj[q][o] = j0 + 64 * o + lane;
-                    const int jc = jj[q][o] < m ? jj[q][o] : m - 1;
-                    d[q][o] = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), px, py, pz);
-                    if (!(f < nf && jj[q][o] < m)) d[q][o] = __builtin_nan(""); // never kept
+                    d[q][o] = sqdist(ICPMI_SX(sorted, ms, jj[q][o]), ICPMI_SY(sorted, ms, jj[q][o]), ICPMI_SZ(sorted, ms, jj[q][o]), px, py, pz);
+                    if (!(se[q] >= 0 && jj[q][o] < m)) d[q][o] = __builtin_nan(""); // never kept
                 }
             }
 #pragma unroll
@@ -142,7 +185,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restr
                         const int pos = total + __popcll(km & ((1ull << lane) - 1ull));
                         if (pos < kKnnCap) {
                             cand_d[wave][pos] = d[q][o];
-                            cand_j[wave][pos] = (int)perm[jj[q][o]];
+                            cand_j[wave][pos] = jj[q][o]; // sorted position (knn_rank_write translates the winners)
                         }
                     }
                     total += __popcll(km);
@@ -167,7 +210,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restr
         return;
     }
     __builtin_amdgcn_wave_barrier();
-    knn_rank_write(cand_d[wave], cand_j[wave], cand_r[wave], owner[wave], total, k, lane, knn_idx + (size_t)i * k);
+    knn_rank_write(cand_d[wave], cand_j[wave], cand_r[wave], owner[wave], total, k, lane, knn_idx + (size_t)i * k, perm);
 }
 
 } // namespace icpmi

@@ -1691,8 +1691,11 @@ __device__ __forceinline__ T wave_sort_asc(T v, int lane)
 // Fast pass: count strictly smaller distances only (one compare per pair).  Without equal
 // distances that count IS the rank; candidates with equal distance get the same count,
 // which the owner table exposes -- then the full (distance, index) order is evaluated.
-__device__ __forceinline__ void knn_rank_write(const double *cd, const int *cj, int *cr, int *own, const int total,
-                                               const int k, const int lane, int *__restrict__ out)
+// With `perm`, cj[] holds SORTED positions (the scan did not wait for the index of every candidate): translated for the
+// k winners only, or for all candidates when the index has to break a tie.
+__device__ __forceinline__ void knn_rank_write(const double *cd, int *cj, int *cr, int *own, const int total,
+                                               const int k, const int lane, int *__restrict__ out,
+                                               const unsigned *__restrict__ perm = nullptr)
 {
     bool clash = false;
     for (int e = lane; e < total; e += 64) {
@@ -1707,9 +1710,13 @@ __device__ __forceinline__ void knn_rank_write(const double *cd, const int *cj, 
     if (__ballot(clash) == 0ull) {
         for (int e = lane; e < total; e += 64) {
             const int r = cr[e];
-            if (r < k) out[r] = cj[e];
+            if (r < k) out[r] = perm ? (int)perm[cj[e]] : cj[e];
         }
         return;
+    }
+    if (perm) {
+        for (int e = lane; e < total; e += 64) cj[e] = (int)perm[cj[e]];
+        __builtin_amdgcn_wave_barrier();
     }
     for (int e = lane; e < total; e += 64) {
         const double d = cd[e];
@@ -2233,27 +2240,95 @@ __global__ __launch_bounds__(256) void k_normals_from_knn(const double *__restri
     const int *nb = knn_idx + (size_t)i * k;
     double nx = 0.0, ny = 0.0, nz = 1.0; // icp.hpp:34-37
     if (cnt >= 3) {
+        // The neighbours are fetched five at a time -- indices, then coordinates, each batch's loads in flight
+        // together -- and summed one after the other in list order as the reference does: as one dependent chain of
+        // index load -> coordinate load per neighbour the two passes were 80 round trips to memory (44 us per 100k rows).
+        constexpr int kB = 5;
+        constexpr int kAll = 20; // the reference's k (icp.hpp:170): the whole list in registers, two round trips in all
         double cx = 0.0, cy = 0.0, cz = 0.0; // icp.hpp:40-44
-        for (int a = 0; a < cnt; ++a) {
-            const int j = (unsigned)nb[a] < (unsigned)m ? nb[a] : self; // rows with NaN coordinates have no list
-            cx += pts[3 * j];
-            cy += pts[3 * j + 1];
-            cz += pts[3 * j + 2];
-        }
+        double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0; // icp.hpp:47-52
         const double kd = (double)cnt;
+        if (cnt <= kAll) {
+            int j[kAll];
+            double x[kAll], y[kAll], z[kAll];
+#pragma unroll
+            for (int b = 0; b < kAll; ++b) j[b] = nb[b < cnt ? b : cnt - 1];
+#pragma unroll
+            for (int b = 0; b < kAll; ++b) {
+                const int jj = (unsigned)j[b] < (unsigned)m ? j[b] : self; // rows with NaN coordinates have no list
+                x[b] = pts[3 * jj];
+                y[b] = pts[3 * jj + 1];
+                z[b] = pts[3 * jj + 2];
+            }
+#pragma unroll
+            for (int b = 0; b < kAll; ++b)
+                if (b < cnt) {
+                    cx += x[b];
+                    cy += y[b];
+                    cz += z[b];
+                }
+            cx /= kd;
+            cy /= kd;
+            cz /= kd;
+#pragma unroll
+            for (int b = 0; b < kAll; ++b)
+                if (b < cnt) {
+                    const double dx = x[b] - cx, dy = y[b] - cy, dz = z[b] - cz;
+                    c00 += dx * dx;
+                    c01 += dx * dy;
+                    c02 += dx * dz;
+                    c11 += dy * dy;
+                    c12 += dy * dz;
+                    c22 += dz * dz;
+                }
+        } else {
+        for (int a0 = 0; a0 < cnt; a0 += kB) {
+            int j[kB];
+            double x[kB], y[kB], z[kB];
+#pragma unroll
+            for (int b = 0; b < kB; ++b) j[b] = nb[a0 + b < cnt ? a0 + b : cnt - 1];
+#pragma unroll
+            for (int b = 0; b < kB; ++b) {
+                const int jj = (unsigned)j[b] < (unsigned)m ? j[b] : self; // rows with NaN coordinates have no list
+                x[b] = pts[3 * jj];
+                y[b] = pts[3 * jj + 1];
+                z[b] = pts[3 * jj + 2];
+            }
+#pragma unroll
+            for (int b = 0; b < kB; ++b)
+                if (a0 + b < cnt) {
+                    cx += x[b];
+                    cy += y[b];
+                    cz += z[b];
+                }
+        }
         cx /= kd;
         cy /= kd;
         cz /= kd;
-        double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0; // icp.hpp:47-52
-        for (int a = 0; a < cnt; ++a) {
-            const int j = (unsigned)nb[a] < (unsigned)m ? nb[a] : self;
-            const double dx = pts[3 * j] - cx, dy = pts[3 * j + 1] - cy, dz = pts[3 * j + 2] - cz;
-            c00 += dx * dx;
-            c01 += dx * dy;
-            c02 += dx * dz;
-            c11 += dy * dy;
-            c12 += dy * dz;
-            c22 += dz * dz;
+        for (int a0 = 0; a0 < cnt; a0 += kB) {
+            int j[kB];
+            double x[kB], y[kB], z[kB];
+#pragma unroll
+            for (int b = 0; b < kB; ++b) j[b] = nb[a0 + b < cnt ? a0 + b : cnt - 1];
+#pragma unroll
+            for (int b = 0; b < kB; ++b) {
+                const int jj = (unsigned)j[b] < (unsigned)m ? j[b] : self;
+                x[b] = pts[3 * jj];
+                y[b] = pts[3 * jj + 1];
+                z[b] = pts[3 * jj + 2];
+            }
+#pragma unroll
+            for (int b = 0; b < kB; ++b)
+                if (a0 + b < cnt) {
+                    const double dx = x[b] - cx, dy = y[b] - cy, dz = z[b] - cz;
+                    c00 += dx * dx;
+                    c01 += dx * dy;
+                    c02 += dx * dz;
+                    c11 += dy * dy;
+                    c12 += dy * dz;
+                    c22 += dz * dz;
+                }
+        }
         }
         const double cov[6] = {c00 / kd, c01 / kd, c02 / kd, c11 / kd, c12 / kd, c22 / kd};
         double v[3];
