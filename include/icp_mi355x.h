@@ -104,6 +104,7 @@ typedef struct {
     int64_t nn_coarse_blocks;                        /* (512-query block, 2048-target split) workgroups launched */
     int64_t nn_pruned_blocks;                        /* of those, skipped by ICPMI_SEARCH_MFMA_PRUNED's box test */
     int64_t small_launches;                          /* iterations run by the small-cloud kernel (search + residuals + pose update in one launch) */
+    int64_t bounded_launches;                        /* passes of the ICP loop searched behind the previous pass's matches (lists instead of coarse minima) */
 } icpmi_profile;
 
 void icpmi_options_default(icpmi_options *opt);     /* device 0, normal_k 20 (icp.hpp:170), search AUTO or the

@@ -58,7 +58,8 @@ class Profile(C.Structure):
                 ("setup_ms", C.c_double),
                 ("nn_pairs", C.c_double), ("nn_recheck_queries", C.c_int64),
                 ("nn_fallback_queries", C.c_int64), ("knn_fallback_rows", C.c_int64),
-                ("nn_coarse_blocks", C.c_int64), ("nn_pruned_blocks", C.c_int64), ("small_launches", C.c_int64)]
+                ("nn_coarse_blocks", C.c_int64), ("nn_pruned_blocks", C.c_int64), ("small_launches", C.c_int64),
+                ("bounded_launches", C.c_int64)]
 
 
 class StreamInfo(C.Structure):

@@ -33,6 +33,7 @@
 #include "nn_mfma.h"
 #include "icp_small.h"
 #include "knn_lists.h"
+#include "nn_bounded.h"
 #include "voxel.h"
 #include "scan_context.h"
 #include "occupancy.h"
@@ -186,6 +187,7 @@ struct icpmi_ctx {
 
     DevBuf cur, nrm, idx, part_d2, part_idx, partials, history, stage_a, stage_b, stage_c, d2out;
     DevBuf knn_idx, slotmin, fb_list;         // k-NN lists, slot minima, rows for the exact fallback
+    DevBuf nn_lists;                          // bounded 1-NN pass: per row bound, threshold, count, listed columns (nn_bounded.h)
     DevBuf nrm_sorted;                        // small-cloud kernel: the target normals in Morton order (SoA, stride nn_ms)
     DevBuf vox_keys, vox_vals, vox_out;             // voxel filter: 64-bit keys (in/out/unique), values + run data, result
     DevBuf stream_prev, stream_cur, f32_stage;      // odometry stream: previous / current filtered scan; float32 upload staging
@@ -563,18 +565,58 @@ float *coarse_clock_buffer(icpmi_ctx *ctx, int n, int splits)
 #endif
 }
 
+// ICPMI_NN_BOUNDED=0: every pass of the ICP loop keeps its coarse minima and certifies afterwards (round 2's form)
+bool nn_bounded_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("ICPMI_NN_BOUNDED");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// `bounded`: d_idx holds the rows' matches of the previous pass (nn_bounded.h)
 int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx, double *d_d2,
                    const IcpState *st, const double *d_tgt = nullptr, const double *d_nrm = nullptr,
-                   double *d_partials = nullptr, int pruned_pass = -1)
+                   double *d_partials = nullptr, int pruned_pass = -1, bool bounded = false)
 {
     const int splits = ctx->nn_splits;
     int rc;
-    if ((rc = reserve(ctx, ctx->coarse, coarse_bytes(splits, n)))) return rc;
     const SplitFrame *frames = (const SplitFrame *)ctx->frames.p;
     const unsigned *perm = (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m;
     unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);
     Range range("icpmi:nn_search");
     StageTimer t(ctx, ST_NN);
+    if (bounded && pruned_pass < 0 && d_tgt && d_partials && !d_d2 && resolve_waves(n) == 0 && !coarse_half_units(ctx, n, splits) &&
+        nn_bounded_enabled()) {
+        constexpr size_t kRowBytes = sizeof(double) + 2 * sizeof(float) + sizeof(int) + sizeof(unsigned) * kNnEntCap;
+        if ((rc = reserve(ctx, ctx->nn_lists, kRowBytes * (size_t)n + 64))) return rc;
+        double *ub_row = (double *)ctx->nn_lists.p;
+        unsigned *ent_row = (unsigned *)(ub_row + n);            // (8-byte aligned: read two words at a time)
+        float *ubf_row = (float *)(ent_row + (size_t)kNnEntCap * n), *sqf_row = ubf_row + n;
+        int *cnt_row = (int *)(sqf_row + n);
+        hipLaunchKernelGGL(k_nn_bounds, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_qry, n, d_tgt, m, (const int *)d_idx,
+                           ub_row, ubf_row, sqf_row, cnt_row, st);
+        {
+            StageTimer tc(ctx, ST_COARSE);
+            hipLaunchKernelGGL((k_nn_coarse_bounded<kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
+                               dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,
+                               KnnLists{ubf_row, sqf_row, cnt_row, ent_row, kNnEntCap}, st);
+            ctx->prof.nn_coarse_blocks += (int64_t)((n + kCoarseQueries - 1) / kCoarseQueries) * splits;
+        }
+        hipLaunchKernelGGL(k_nn_resolve_bounded, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, d_qry, n,
+                           (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, splits, frames, (const double *)ub_row,
+                           (const int *)cnt_row, (const unsigned *)ent_row, d_idx,
+                           // (the statistics are two words every wave with something to report adds to: with one row in a
+                           // hundred listing a second slot that is most waves of a pass, and the same-address atomics were
+                           // 25 of the kernel's 55 us -- counted when a profile is asked for only)
+                           ctx->opt.profile ? counters : (unsigned long long *)nullptr, d_tgt, d_nrm, d_partials, st);
+        ctx->prof.nn_pairs += (double)n * (double)m;
+        ctx->prof.bounded_launches += 1;
+        HIP_TRY(ctx, hipGetLastError());
+        return ICPMI_OK;
+    }
+    if ((rc = reserve(ctx, ctx->coarse, coarse_bytes(splits, n)))) return rc;
     {
         StageTimer tc(ctx, ST_COARSE); // the dominant kernel alone (matches rocprofv3's per-kernel average)
         if (pruned_pass >= 0) {
@@ -733,7 +775,7 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                 float *thr_row = (float *)(t_row + chunk);
                 int *cnt_row = (int *)(thr_row + chunk);
                 unsigned *ent_row = (unsigned *)(cnt_row + chunk);
-                const KnnLists kl{thr_row, cnt_row, ent_row};
+                const KnnLists kl{thr_row, nullptr, cnt_row, ent_row, kKnnEntCap};
                 hipLaunchKernelGGL(k_knn_prebound, dim3((nq + kPreRows - 1) / kPreRows), dim3(256), 0, s, sorted, m, ctx->nn_ms, k, (int)c0, nq,
                                    (const NnFrame *)ctx->nn_misc.p, t_row, thr_row, cnt_row);
                 if (coarse_half_units(ctx, nq, splits)) {
@@ -1046,13 +1088,20 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     const int splits = ctx->nn_splits;
     int pass_no = 0; // coarse passes queued so far: selects the work counter (see k_nn_coarse_list)
     const unsigned *src_perm = nullptr;
-    if (pruned) {
-        size_t sort_bytes = 0;
+    // All-pairs engine, general kernels: the rows are taken in Morton order too (the order is internal here as well).  A
+    // tile of 32 neighbouring rows has its matches in one or two splits, so the bounded pass's epilogue (nn_bounded.h)
+    // finds nothing to list in the other 47 and leaves by its short path: with rows in the caller's order half of all
+    // (tile, split) pairs listed something (k_nn_coarse_bounded 305 -> 295 us on C3, k_nn_resolve_bounded 29 -> 28).
+    const bool sorted_rows_loop = fused && !pruned && !small && n > 0 && resolve_waves(n) == 0 && !coarse_half_units(ctx, n, splits);
+    size_t sort_bytes = 0;
+    if (pruned || sorted_rows_loop) {
         HIP_TRY(ctx, sort_pairs_u32(nullptr, &sort_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned)n, s));
         const int bblocks = std::max(1, std::min(256, (n + 255) / 256));
         if ((rc = reserve(ctx, ctx->src_sort, sizeof(unsigned) * 4 * (size_t)n))) return rc;
         if ((rc = reserve(ctx, ctx->sort_tmp, sort_bytes))) return rc; // the target's sort is done (stream order)
         if ((rc = reserve(ctx, ctx->bbox_part, sizeof(double) * 6 * (size_t)bblocks))) return rc;
+    }
+    if (pruned) {
         if ((rc = reserve(ctx, ctx->blk_lists, sizeof(int) * (size_t)qblocks * ((size_t)splits + 1)))) return rc;
         if ((rc = reserve(ctx, ctx->work, sizeof(unsigned) * (size_t)qblocks * (size_t)splits))) return rc;
         blk_cnt = (int *)ctx->blk_lists.p;
@@ -1060,6 +1109,9 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         work = (unsigned *)ctx->work.p;
         work_cnt = (unsigned *)((char *)ctx->nn_misc.p + 160);
         HIP_TRY(ctx, hipMemsetAsync(work_cnt, 0, 2 * sizeof(unsigned), s));
+    }
+    if (pruned || sorted_rows_loop) {
+        const int bblocks = std::max(1, std::min(256, (n + 255) / 256));
         NnFrame *sframe = (NnFrame *)((char *)ctx->nn_misc.p + 64);
         unsigned *keys_in = (unsigned *)ctx->src_sort.p, *keys_out = keys_in + n, *vals_in = keys_in + 2 * (size_t)n,
                  *perm = keys_in + 3 * (size_t)n;
@@ -1081,7 +1133,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                                blk_cnt, blk_list, work, work_cnt /* pass 0 reads counter 0 */);
         else
             hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, d_src,
-                               cur, n, st, 1, 0);
+                               cur, n, st, 1, 0, src_perm);
     }
 
     unsigned long long *small_clocks = nullptr;
@@ -1120,7 +1172,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         const bool fuse_finish = !sharded && !pruned && n > 0 && !final_pass && fuse_finish_enabled();
         if (n > 0 && fused) {
             if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, st, d_tgt, nrm, partials,
-                                     pruned ? pass_no : -1))) return r2;
+                                     pruned ? pass_no : -1, pass_no > 0 /* the rows' previous matches are in idx */))) return r2;
             ++pass_no;
         } else if (n > 0) {
             if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, st))) return r2;
@@ -1576,7 +1628,7 @@ void icpmi_destroy(icpmi_ctx *ctx)
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
     for (DevBuf *b : {&ctx->cur, &ctx->nrm, &ctx->idx, &ctx->part_d2, &ctx->part_idx, &ctx->partials,
                       &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out, &ctx->src_sort, &ctx->blk_lists, &ctx->work,
-                      &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin, &ctx->nrm_sorted,
+                      &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin, &ctx->nn_lists, &ctx->nrm_sorted,
                       &ctx->fb_list, &ctx->sort_keys, &ctx->sort_tmp, &ctx->tgt_sorted, &ctx->frames, &ctx->vox_keys,
                       &ctx->vox_vals, &ctx->vox_out, &ctx->stream_prev, &ctx->stream_cur, &ctx->f32_stage, &ctx->grid_set,
                       &ctx->grid_in, &ctx->grid_out, &ctx->grid_cnt, &ctx->world})

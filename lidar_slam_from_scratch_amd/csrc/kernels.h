@@ -456,9 +456,10 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_solve(const double *_
 
 // out = in * R^T + t^T with T read from device memory (st->delta or a staged matrix).
 // which: 0 = st->delta, 1 = st->total
+// perm (may be null): out row i is made from in row perm[i] (the ICP loop takes its source rows in Morton order)
 __global__ __launch_bounds__(256) void k_transform(const double *in, double *out, int n,
                                                    const IcpState *__restrict__ st, int which,
-                                                   int honour_done)
+                                                   int honour_done, const unsigned *__restrict__ perm = nullptr)
 {
     if (honour_done && st->done) return;
     const double *T = which ? st->total : st->delta;
@@ -466,7 +467,8 @@ __global__ __launch_bounds__(256) void k_transform(const double *in, double *out
     const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
     const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+        const size_t ii = perm ? perm[i] : (unsigned)i;
+        const double x = in[3 * ii], y = in[3 * ii + 1], z = in[3 * ii + 2];
         out[3 * i] = ((x * r00 + y * r01) + z * r02) + t0;
         out[3 * i + 1] = ((x * r10 + y * r11) + z * r12) + t1;
         out[3 * i + 2] = ((x * r20 + y * r21) + z * r22) + t2;

@@ -1,0 +1,237 @@
+// nn_bounded.h -- the correspondence search of an ICP pass that has a previous pass behind it (icp.hpp:181-196 from
+// the second iteration on), all-pairs MFMA engine, round 3.
+//
+// Every row of the moved source still knows the target it was matched with one pass ago.  That target is a real
+// target, so its exact distance to the moved row, ub, bounds the new nearest-neighbour distance from above BEFORE
+// anything is searched -- and with the bound in hand the coarse pass no longer has to keep its minima:
+//   k_nn_bounds          ub(row) = |row - target[previous match]|^2 exactly (and its fp32 images, rounded up)
+//   k_nn_coarse_bounded  the all-pairs pass with the MODE 3 epilogue: the columns (slots of 64 sorted targets) whose
+//                        minimum is <= tau_s(ub(row)), the bound on the coarse value of any target of split s within
+//                        ub (nn_mfma.h), are listed per row, 16 columns to a word -- one word per row, rarely two,
+//                        instead of 6 B per (row, split): 29 MB written and read back per C3 pass before, 2.9 GB at
+//                        1M x 1M
+//   k_nn_resolve_bounded exact fp64 scan of the listed slots (the reference's operation order), smallest distance,
+//                        ties to the lowest ORIGINAL index, against the previous match as the incumbent
+// Every target at exact distance <= the final minimum <= ub has a coarse value <= its split's tau_s(ub) (the error
+// bound of nn_mfma.h), so its slot is listed and it is scanned: the result is the exact nearest neighbour with the reference's
+// tie rule -- what k_nn_resolve returns, bit for bit -- and there is no certificate left to run, because the bound was
+// applied before the search instead of after it.  A row whose list does not fit (more than kNnEntCap words or
+// kNnSlotCap slots: a pose update so large that ub spans many slots) is searched exhaustively instead, split by
+// split behind the split's bounding box and slot by slot behind the slot's (scan_split) with the incumbent's distance
+// as the radius: slower for that row (a few dozen slot scans instead of one or two), never wrong.  The first pass of a
+// call has no previous match and runs k_nn_coarse<0> + k_nn_resolve.
+// The normal-equation terms are formed and summed exactly as in k_nn_resolve<16> (resolve_finish), so the partial rows,
+// hence history and pose, are bit-identical to the unbounded pass's.
+#pragma once
+#include "nn_mfma.h"
+
+namespace icpmi {
+
+constexpr int kNnSlotCap = 16; // listed slots scanned per row
+
+__global__ __launch_bounds__(256) void k_nn_bounds(const double *__restrict__ cur, int n, const double *__restrict__ tgt_orig,
+                                                   int m, const int *__restrict__ idx_prev,
+                                                   double *__restrict__ ub_row, float *__restrict__ ubf_row,
+                                                   float *__restrict__ sqf_row, int *__restrict__ cnt_row,
+                                                   const IcpState *__restrict__ st)
+{
+    if (st && st->done) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double px = cur[3 * i], py = cur[3 * i + 1], pz = cur[3 * i + 2];
+    const int j = idx_prev[i];
+    // fp32 images for the coarse pass, rounded up.  A row with a NaN or infinite coordinate has no neighbour
+    // (kdtree.hpp:125): NaN, under which nothing is listed.  No previous match (every target non-finite ...): +Inf,
+    // everything is listed.
+    double ub = __builtin_inf();
+    float ubf = __builtin_nanf(""), sqf = 0.f;
+    if (finite3(px, py, pz)) {
+        if ((unsigned)j < (unsigned)m) ub = sqdist(tgt_orig[3 * j], tgt_orig[3 * j + 1], tgt_orig[3 * j + 2], px, py, pz);
+        ubf = (float)ub;
+        ubf = (double)ubf < ub ? __uint_as_float(__float_as_uint(ubf) + 1u) : ubf; // (ub >= 0; Inf stays Inf)
+        sqf = __builtin_amdgcn_sqrtf(ubf);
+        sqf = sqf < 3.0e38f ? __uint_as_float(__float_as_uint(sqf) + 2u) : sqf;   // (1 ulp of v_sqrt_f32 and one more)
+    }
+    ub_row[i] = ub;
+    ubf_row[i] = ubf;
+    sqf_row[i] = sqf;
+    cnt_row[i] = 0;
+}
+
+// Q = 16 queries per wave, the lane layout, workgroup shape and sums of k_nn_resolve<16>.
+__global__ __launch_bounds__(64 * kResolveWW) void k_nn_resolve_bounded(
+    const double *__restrict__ qry, int n, const double *__restrict__ sorted, const unsigned *__restrict__ perm, int m, int ms,
+    int splits, const SplitFrame *__restrict__ frames, const double *__restrict__ ub_row, const int *__restrict__ cnt_row,
+    const unsigned *__restrict__ ent_row, int *__restrict__ idx /* in: previous match, out: this pass's */,
+    unsigned long long *__restrict__ counters, const double *__restrict__ tgt_orig, const double *__restrict__ nrm,
+    double *__restrict__ partials, const IcpState *__restrict__ st)
+{
+    constexpr int Q = 16, ROUNDS = Q / 4;
+    static_assert(kNnEntCap == 8, "two words per sub-lane");
+    __shared__ int flist[kResolveWW][Q][kNnSlotCap];
+    if (st && st->done) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & (Q - 1), sub = lane / Q;
+    const int l16 = lane & 15, quarter = lane >> 4;
+    const int qbase = (blockIdx.x * kResolveWW + wave) * Q;
+    const int i = qbase + ql; // waves past the end run on a clamped query and write nothing
+    const bool valid = i < n;
+    const int ic = valid ? i : n - 1;
+    const double px = qry[3 * ic], py = qry[3 * ic + 1], pz = qry[3 * ic + 2];
+    const bool look = valid && finite3(px, py, pz);
+    const double kMax = 1.7976931348623157e308;
+
+    // the incumbent: the previous match at its exact distance
+    const int jprev = idx[ic];
+    double bd = ub_row[ic];
+    int bj = (unsigned)jprev < (unsigned)m ? jprev : 0x7fffffff;
+    if (!look) bj = 0x7fffffff;
+    if (bj == 0x7fffffff) bd = kMax;
+
+    // the row's list: sub-lane `sub` of query ql holds words 2 sub and 2 sub + 1.  The FIRST listed slot is the lowest bit
+    // of word 0 (a word is only ever appended with a bit set); all but a hundredth of the rows list nothing else.
+    const int cnt = cnt_row[ic];
+    const uint2 w = *reinterpret_cast<const uint2 *>(ent_row + (size_t)ic * kNnEntCap + 2 * sub);
+    const unsigned w0 = (look && 2 * sub < cnt) ? w.x : 0u, w1 = (look && 2 * sub + 1 < cnt) ? w.y : 0u;
+    const int mine = __popc(w0 & 0xFFFFu) + __popc(w1 & 0xFFFFu);
+    int incl = mine;
+    { const int o = __shfl_up(incl, 16, 64); incl += sub >= 1 ? o : 0; }
+    { const int o = __shfl_up(incl, 32, 64); incl += sub >= 2 ? o : 0; }
+    const int nsl = __shfl(incl, 48 + ql, 64); // listed slots of query ql (every sub-lane of the query knows it)
+    auto word_base = [](unsigned word) -> int { return (int)(word >> 17) * kCols + (int)((word >> 16) & 1u) * 16; };
+    const int first_slot = word_base(w0) + ((w0 & 0xFFFFu) ? __ffs((int)(w0 & 0xFFFFu)) - 1 : 0); // (valid in sub-lane 0)
+    // more words or slots than fit -> the exhaustive search below.  (A finite row with a previous match always lists that
+    // match's slot; one without lists everything.)
+    const bool over = look && (cnt > kNnEntCap || nsl > kNnSlotCap);
+    const int nsl_eff = over ? 0 : nsl;
+#if defined(ICPMI_NNB_STOP) && ICPMI_NNB_STOP == 1 /* timing experiments only (WRONG results): where the kernel's time goes */
+    if (nsl_eff >= 0) { if (valid && sub == 0) idx[i] = first_slot + (int)bd; return; }
+#endif
+
+    // exact evaluation of the listed slots, one query per quarter-wave and round (lane takes l16, l16+16, ...: coalesced).
+    // The first slot of the quarter's four queries is scanned with the loads of all four rounds in flight together, the
+    // original indices beside the coordinates (as a chain of dependent trips this kernel was twice as long as the one
+    // it replaces: it waits on memory, not on instructions).
+    double d[ROUNDS];
+    int jo[ROUNDS], ns[ROUNDS];
+    double qx[ROUNDS], qy[ROUNDS], qz[ROUNDS];
+    auto scan_slot = [&](const int r, const int slot, const bool act) {
+        const int j0 = (slot / kCols) * kSplitTargets + (slot % kCols) * kSlotTargets + l16;
+#pragma unroll
+        for (int o = 0; o < kSlotTargets / 16; ++o) {
+            // (no clamp: a slot's 64 positions lie inside the sorted copy's and perm's allocation; padding is dropped by jj < m)
+            const int jj = j0 + 16 * o;
+            const int oj = (int)perm[jj < m ? jj : m - 1];
+            const double dd = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), qx[r], qy[r], qz[r]);
+            if (act && jj < m && (dd < d[r] || (dd == d[r] && oj < jo[r]))) {
+                d[r] = dd;
+                jo[r] = oj;
+            }
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int src = quarter * ROUNDS + r; // the query this quarter scans in round r (a lane with sub == 0)
+        qx[r] = __shfl(px, src, 64), qy[r] = __shfl(py, src, 64), qz[r] = __shfl(pz, src, 64);
+        ns[r] = __shfl(nsl_eff, src, 64);
+        d[r] = kMax;
+        jo[r] = 0x7fffffff;
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) scan_slot(r, __shfl(first_slot, quarter * ROUNDS + r, 64), ns[r] > 0);
+#if defined(ICPMI_NNB_STOP) && ICPMI_NNB_STOP == 2
+    if (nsl_eff >= 0) { if (valid && sub == 0) idx[i] = jo[0] + jo[1] + jo[2] + jo[3] + (int)(d[0] + d[1] + d[2] + d[3]); return; }
+#endif
+    if (__ballot(nsl_eff > 1) != 0ull) { // further slots: through LDS, sub-lane `sub` expands its two words
+        int pos = incl - mine;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned word = h ? w1 : w0;
+            unsigned msk = word & 0xFFFFu;
+            const int base = word_base(word);
+            while (msk) {
+                if (pos < kNnSlotCap) flist[wave][ql][pos] = base + __ffs((int)msk) - 1;
+                ++pos;
+                msk &= msk - 1u;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            for (int t = 1; __ballot(t < ns[r]) != 0ull; ++t)
+                scan_slot(r, t < ns[r] ? flist[wave][quarter * ROUNDS + r][t] : 0, t < ns[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+#pragma unroll
+        for (int x = 1; x < 16; x <<= 1) {
+            const double od = __shfl_xor(d[r], x, 64);
+            const int oj = __shfl_xor(jo[r], x, 64);
+            if (od < d[r] || (od == d[r] && oj < jo[r])) {
+                d[r] = od;
+                jo[r] = oj;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        // query ql was scanned by quarter ql / ROUNDS in round ql % ROUNDS
+        const double rd = __shfl(d[r], (ql / ROUNDS) * 16, 64);
+        const int rj = __shfl(jo[r], (ql / ROUNDS) * 16, 64);
+        if ((ql % ROUNDS) == r && look && (rd < bd || (rd == bd && rj < bj))) {
+            bd = rd;
+            bj = rj;
+        }
+    }
+
+#if defined(ICPMI_NNB_STOP) && ICPMI_NNB_STOP == 3
+    if (nsl_eff >= 0) { if (valid && sub == 0) idx[i] = bj + (int)bd; return; }
+#endif
+    // rows whose list did not fit: every split whose bounding box is within the incumbent's distance, its slots culled
+    // by their boxes (scan_split), nearest-first is not needed for correctness -- the radius only shrinks
+    unsigned extra_splits = 0;
+    unsigned long long pend = __ballot(over && sub == 0);
+    while (pend) { // rare; wave-uniform loop
+        const int L = __ffsll((long long)pend) - 1;
+        pend &= pend - 1;
+        const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
+        double qd = __shfl(bd, L, 64);
+        int qj = __shfl(bj, L, 64);
+        for (int s0 = 0; s0 < splits; s0 += 64) {
+            bool keep = false;
+            if (s0 + lane < splits) {
+                const SplitFrame &f = frames[s0 + lane];
+                double lb = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double q = px_sel(a, qx, qy, qz);
+                    const double g1 = f.lo[a] - q, g2 = q - f.hi[a];
+                    const double g = g1 > g2 ? (g1 > 0.0 ? g1 : 0.0) : (g2 > 0.0 ? g2 : 0.0);
+                    lb += g * g;
+                }
+                keep = !(lb * (1.0 - 1e-9) > qd); // (an empty split's box is inverted: infinitely far)
+            }
+            unsigned long long smask = __ballot(keep);
+            while (smask) {
+                const int sL = s0 + __ffsll((long long)smask) - 1;
+                smask &= smask - 1;
+                scan_split<ICPMI_RESOLVE_SCANBATCH>(sorted, perm, m, ms, reinterpret_cast<const double *>(frames + splits), sL, qx, qy,
+                                                    qz, qd, lane, qd, qj);
+            }
+        }
+        if ((lane & (Q - 1)) == (L & (Q - 1))) {
+            bd = qd;
+            bj = qj;
+        }
+        if (lane == L) ++extra_splits;
+    }
+
+#if defined(ICPMI_NNB_STOP) && ICPMI_NNB_STOP == 4
+    if (nsl_eff >= 0) { if (valid && sub == 0) idx[i] = bj + (int)bd; return; }
+#endif
+    const unsigned extra_slots = (sub == 0 && look && !over && nsl > 1) ? (unsigned)(nsl - 1) : 0u;
+    resolve_finish<Q>(lane, wave, ql, sub, i, valid, bd, bj, px, py, pz, m, idx, nullptr, counters, extra_slots, extra_splits,
+                      tgt_orig, nrm, partials, -1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);
+}
+
+} // namespace icpmi

@@ -431,20 +431,28 @@ __device__ __forceinline__ float tag_low5(float x, unsigned tag)
 // MODE 1: k-NN epilogue  -> slotmin[query][split*32 + column], every column minimum kept (bf16, rounded down)
 // MODE 2: k-NN epilogue for rows that come with a bound (knn_lists.h): the columns whose minimum is <= the
 //         row's threshold are LISTED per row, 16 columns to a word; nothing else is written
+// MODE 3: the same lists for the rows of an ICP pass (nn_bounded.h), the threshold formed per (row, SPLIT) from the row's
+//         distance bound and the split's own frame term -- the bound that holds for every split carries 52 u a^2 with
+//         a = the whole target's extent, which on a 100 m cloud is a third of a nearest-neighbour distance squared and
+//         listed a second slot for a third of the rows
 // QT = 32-query tiles per wave (even); WAVES = waves per workgroup.  (Tried and dropped, see
 // scripts/micro/README.md: issuing a tile's min3 one tile behind its MFMAs, keeping the next B chunk
 // in flight in registers, QT = 4: none beat this form, all cost occupancy.)
 //
 // The three parts of a wave's work on 32*QT queries against one split, shared by the kernels below.
 
-// MODE 2's output: per row a count and up to kKnnEntCap words (split << 17 | half << 16 | mask of the 16 columns
+// MODE 2's output: per row a count and up to `cap` words (split << 17 | half << 16 | mask of the 16 columns
 // split*32 + half*16 + bit whose minimum is under thr[row]); rows are numbered from the launch's first row.
 constexpr int kKnnEntCap = 32;
 struct KnnLists {
-    const float *thr; // [rows] bound on the coarse value of anything the row needs to look at
-    int *cnt;         // [rows] words appended (may exceed kKnnEntCap: the row then goes to the exact kernel)
-    unsigned *ent;    // [rows][kKnnEntCap]
+    const float *thr; // [rows] MODE 2: bound on the coarse value of anything the row needs to look at; MODE 3: the row's
+                      //        distance bound itself, fp32 rounded up
+    const float *sq;  // [rows] MODE 3: its square root, rounded up
+    int *cnt;         // [rows] words appended (may exceed `cap`: the row then takes its reader's exhaustive path)
+    unsigned *ent;    // [rows][cap]
+    int cap;          // words per row: kKnnEntCap (normal estimation), kNnEntCap (the ICP loop's bounded 1-NN pass)
 };
+constexpr int kNnEntCap = 8;
 
 // A operands.  Each lane builds the 16-slot bf16 row of ONE query (lane-per-query: coalesced fp64
 // loads, pieces computed once), rows go through `rows` (64 rows x 32 B of LDS private to the
@@ -455,7 +463,7 @@ template <int QT, bool QSOA>
 __device__ __forceinline__ void coarse_build_a(uint4 *rows, const int lane, const int q0,
                                                const double *__restrict__ qry, const int n, const size_t qstride,
                                                const double c0, const double c1, const double c2,
-                                               bf16x8 (&afrag)[QT], float (&pn)[(QT + 1) / 2])
+                                               bf16x8 (&afrag)[QT], float (&pn)[(QT + 1) / 2], float (&p2)[(QT + 1) / 2])
 {
     static_assert(QT == 1 || QT % 2 == 0, "operands are staged 64 queries at a time (QT = 1: 32, by both half-waves)");
 #pragma unroll
@@ -474,6 +482,7 @@ __device__ __forceinline__ void coarse_build_a(uint4 *rows, const int lane, cons
             const float ty = __uint_as_float(yh << 16) + __uint_as_float(ym << 16);
             const float tz = __uint_as_float(zh << 16) + __uint_as_float(zm << 16);
             pn[gq] = (tx * tx + ty * ty) + tz * tz;
+            p2[gq] = pn[gq]; // |P|^2 whole (MODE 3's frame term)
         }
         // leading piece of |P|^2 (truncated: exact difference) goes through the matrix core,
         // the epilogue adds the rest
@@ -521,13 +530,14 @@ template <int MODE, int QT>
 __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const int q0, const int s, const int nsplits,
                                                 const int n, const f32x16 (&m)[QT], const float (&pn)[(QT + 1) / 2],
                                                 float2 *__restrict__ coarse, float *__restrict__ slotmin,
-                                                const KnnLists &kl)
+                                                const KnnLists &kl, const float (&thr)[(QT + 1) / 2])
 {
     const int ql = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         float thr_q = 0.f;
         if (MODE == 2) thr_q = kl.thr[q0 + t * 32 + ql < n ? q0 + t * 32 + ql : n - 1];
+        if (MODE == 3) thr_q = __shfl(thr[t >> 1], (t & 1) * 32 + ql, 64); // (formed lane-per-query like pn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + ql] = m[t][r];
         __builtin_amdgcn_wave_barrier();
@@ -546,7 +556,7 @@ __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const
         }
         __builtin_amdgcn_wave_barrier();
         const int iq = q0 + t * 32 + ql;
-        if (MODE == 2) {
+        if (MODE == 2 || MODE == 3) {
             // Nearly every (row, split) pair has nothing under the row's bound: one minimum over the lane's 16
             // columns, one compare, one ballot.  (+Inf / NaN of a far-away or NaN row become kBig like in MODE 1;
             // such a row's bound is FLT_MAX, so it lists everything and is handed to the exact kernel.)
@@ -561,7 +571,7 @@ __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const
 #pragma unroll
                     for (int c = 0; c < 16; ++c) mask |= min_raw(v[c] + pnq, kBig) <= thr_q ? (1u << c) : 0u;
                     const int pos = atomicAdd(kl.cnt + iq, 1);
-                    if (pos < kKnnEntCap) kl.ent[(size_t)iq * kKnnEntCap + pos] = ((unsigned)s << 17) | ((unsigned)half << 16) | mask;
+                    if (pos < kl.cap) kl.ent[(size_t)iq * kl.cap + pos] = ((unsigned)s << 17) | ((unsigned)half << 16) | mask;
                 }
             }
         } else if (MODE == 1) {
@@ -621,7 +631,7 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
                                             const uint4 *__restrict__ Bpack,
                                             const SplitFrame *__restrict__ frames,
                                             float2 *__restrict__ coarse, float *__restrict__ slotmin,
-                                            const KnnLists kl = KnnLists{nullptr, nullptr, nullptr})
+                                            const KnnLists kl = KnnLists{nullptr, nullptr, nullptr, nullptr, 0})
 {
     constexpr int THREADS = 64 * WAVES;
     constexpr int CHUNK16 = kChunkTiles * 64;  // uint4 per staged chunk (32 KiB)
@@ -639,8 +649,24 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
     const double c0 = frames[s].c[0], c1 = frames[s].c[1], c2 = frames[s].c[2];
 
     bf16x8 afrag[QT];
-    float pn[(QT + 1) / 2];
-    coarse_build_a<QT, QSOA>(lds + wave * (64 * 2), lane, q0, qry, n, qstride, c0, c1, c2, afrag, pn);
+    float pn[(QT + 1) / 2], p2[(QT + 1) / 2], thr[(QT + 1) / 2];
+    coarse_build_a<QT, QSOA>(lds + wave * (64 * 2), lane, q0, qry, n, qstride, c0, c1, c2, afrag, pn, p2);
+#pragma unroll
+    for (int gq = 0; gq < (QT + 1) / 2; ++gq) {
+        thr[gq] = 0.f;
+        if (MODE == 3) {
+            // tau_s(d) of nn_mfma.h's header for d = the row's bound, in fp32 with every input rounded up: a >= |p - c_s| + rho_s
+            // from the represented point (within 2^-16 of the true one) and the split's radius, 1e-4 over; the last factor
+            // covers this evaluation's own roundings and tau_from_a's 5e-6.  A NaN bound (a row with a non-finite coordinate)
+            // gives a NaN threshold, under which nothing is; an infinite one (no previous match) lists everything.
+            const int ql = QT == 1 ? (lane & 31) : lane;
+            const int iq = q0 + gq * 64 + ql < n ? q0 + gq * 64 + ql : n - 1;
+            const float ubf = kl.thr[iq], sqf = kl.sq[iq];
+            const float a = (__builtin_amdgcn_sqrtf(p2[gq]) + (float)frames[s].rho) * 1.0001f;
+            const float eps = 1.5260e-05f * a;
+            thr[gq] = ((ubf + eps * (2.f * sqf + eps)) + (float)(kArithBound * 5.9604644775390625e-08) * (a * a)) * 1.00002f;
+        }
+    }
     f32x16 m[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t)
@@ -669,7 +695,7 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
 
     __syncthreads(); // every wave is done with the B operands
     coarse_epilogue<MODE, QT>(reinterpret_cast<float *>(lds) + wave * (32 * 36), lane, q0, s, nsplits, n, m, pn, coarse,
-                              slotmin, kl);
+                              slotmin, kl, thr);
 #ifdef ICPMI_COARSE_CLOCKS
     if (MODE == 0 && slotmin && threadIdx.x == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(slotmin) + 4 * ((size_t)bx * nsplits + s);
@@ -709,6 +735,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse_rows(
 {
     __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
     coarse_unit<2, QT, WAVES, true>(lds, blockIdx.x, blockIdx.y, gridDim.y, rows, n, qstride, Bpack, frames, nullptr, nullptr, kl);
+}
+
+// all pairs, the moved source rows of an ICP pass that come with a bound (nn_bounded.h), MODE 3
+template <int QT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_nn_coarse_bounded(
+    const double *__restrict__ qry, int n, const uint4 *__restrict__ Bpack,
+    const SplitFrame *__restrict__ frames, KnnLists kl, const IcpState *__restrict__ st)
+{
+    if (st && st->done) return;
+    __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
+    coarse_unit<3, QT, WAVES>(lds, blockIdx.x, blockIdx.y, gridDim.y, qry, n, 0, Bpack, frames, nullptr, nullptr, kl);
 }
 
 // (Measured and not kept, scripts/micro/README.md: a RESIDENT form -- one 16-wave workgroup per CU stages a
@@ -1223,6 +1260,95 @@ __device__ __forceinline__ void resolve_certify(const float (&pv)[KEEP > 0 ? KEE
     }
 }
 
+#ifndef ICPMI_RESOLVE_WW
+#define ICPMI_RESOLVE_WW 4 /* waves per workgroup = Q * WW queries per partial row of normal-equation terms */
+#endif
+constexpr int kResolveWW = ICPMI_RESOLVE_WW;
+// The end of the Q-queries-per-wave resolve kernels (k_nn_resolve, k_nn_resolve_bounded): results out, counters, and the
+// fused residual + normal-equation terms.  (jspec, q*, n*): the matched target and normal gathered ahead for target
+// `jspec` (< 0: nothing was gathered).
+template <int Q>
+__device__ __forceinline__ void resolve_finish(const int lane, const int wave, const int ql, const int sub, const int i,
+                                               const bool valid, const double bd, const int bj, const double px,
+                                               const double py, const double pz, const int m, int *__restrict__ idx,
+                                               double *__restrict__ d2out, unsigned long long *__restrict__ counters,
+                                               const unsigned extra_slots, const unsigned extra_splits,
+                                               const double *__restrict__ tgt_orig, const double *__restrict__ nrm,
+                                               double *__restrict__ partials, const int jspec, double q0, double q1,
+                                               double q2, double n0, double n1, double n2)
+{
+    if (valid && sub == 0) {
+        idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
+        if (d2out) d2out[i] = bd;
+    }
+    if (counters) {
+        unsigned es = extra_slots, ef = extra_splits;
+        for (int off = 32; off > 0; off >>= 1) {
+            es += __shfl_down(es, off, 64);
+            ef += __shfl_down(ef, off, 64);
+        }
+        if (lane == 0 && (es | ef)) {
+            atomicAdd(&counters[0], (unsigned long long)es);
+            atomicAdd(&counters[1], (unsigned long long)ef);
+        }
+    }
+    // fused residual + normal equations (what k_reduce does, icp.hpp:99-120,198-206): the Q
+    // owners of a wave form their J row and b, the 28 sums go wave -> LDS -> one partial row
+    // per workgroup, summed later in a fixed order by k_finish_step
+    if (partials) {
+        // Q rows of 28 terms per wave -> LDS (row stride 29: conflict-free), then lane l sums
+        // column l & 31 over the Q / 2 rows of half l >> 5 and the halves meet with one exchange
+        __shared__ double jrow[kResolveWW][Q][29];
+        __shared__ double red[kResolveWW][28];
+        if (sub == 0) { // each term goes to LDS as it is formed (28 live doubles would cost 2 waves per SIMD)
+            double J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, b = 0.0;
+            if (valid) {
+                const int j = (unsigned)bj < (unsigned)m ? bj : 0;
+                if (j != jspec) { // the certificate found a nearer target
+                    q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
+                    n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
+                }
+                J[0] = py * n2 - pz * n1; // p x n, icp.hpp:105
+                J[1] = pz * n0 - px * n2;
+                J[2] = px * n1 - py * n0;
+                J[3] = n0;
+                J[4] = n1;
+                J[5] = n2;
+                const double e0 = q0 - px, e1 = q1 - py, e2 = q2 - pz;
+                b = (e0 * n0 + e1 * n1) + e2 * n2; // icp.hpp:116
+            }
+            double *row = jrow[wave][ql];
+            int o = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) row[o++] = J[r] * J[c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) row[21 + r] = J[r] * b;
+            row[27] = b * b;
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int c = lane & 31, h = lane >> 5;
+            double v = 0.0;
+            if (c < 28) {
+#pragma unroll
+                for (int r = 0; r < Q / 2; ++r) v += jrow[wave][h * (Q / 2) + r][c];
+            }
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 28) red[wave][lane] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 28) {
+            const int e = threadIdx.x;
+            double v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+#pragma unroll
+            for (int w = 4; w < kResolveWW; ++w) v += red[w][e];
+            partials[(size_t)blockIdx.x * kSumsStride + e] = v;
+        }
+    }
+}
+
 // One wave resolves 16 (or 32) queries.  Lane = (query ql, sub-lane): the sub-lanes share the
 // bookkeeping of a query (each looks at its share of the splits) and each quarter-wave scans one
 // winning slot at a time (lane l16 takes sorted positions l16, l16+16, ... of the slot: three
@@ -1257,10 +1383,6 @@ constexpr int kResolveQ = 16;
 // of a query share its bookkeeping.  Q = 32 halves the waves of a pass (C3: 3,125, all resident
 // at once, where the 6,250 of Q = 16 need a second round at 5 waves per SIMD) at the price of a
 // longer chain per wave (8 scan rounds instead of 4).
-#ifndef ICPMI_RESOLVE_WW
-#define ICPMI_RESOLVE_WW 4 /* waves per workgroup = Q * WW queries per partial row of normal-equation terms */
-#endif
-constexpr int kResolveWW = ICPMI_RESOLVE_WW;
 template <int Q>
 __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu(ICPMI_RESOLVE_OCC, 8))) void k_nn_resolve(
     const double *__restrict__ qry, int n,
@@ -1390,76 +1512,8 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     unsigned extra_slots = 0, extra_splits = 0;
     resolve_certify<SUBS, Q, KEEP, ICPMI_RESOLVE_SCANBATCH>(pv, lane, sub, valid, ic, n, px, py, pz, coarse, splits, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                              bd, bj, extra_slots, extra_splits);
-    if (valid && sub == 0) {
-        idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
-        if (d2out) d2out[i] = bd;
-    }
-    if (counters) {
-        unsigned es = extra_slots, ef = extra_splits;
-        for (int off = 32; off > 0; off >>= 1) {
-            es += __shfl_down(es, off, 64);
-            ef += __shfl_down(ef, off, 64);
-        }
-        if (lane == 0 && (es | ef)) {
-            atomicAdd(&counters[0], (unsigned long long)es);
-            atomicAdd(&counters[1], (unsigned long long)ef);
-        }
-    }
-    // fused residual + normal equations (what k_reduce does, icp.hpp:99-120,198-206): the Q
-    // owners of a wave form their J row and b, the 28 sums go wave -> LDS -> one partial row
-    // per workgroup, summed later in a fixed order by k_finish_step
-    if (partials) {
-        // Q rows of 28 terms per wave -> LDS (row stride 29: conflict-free), then lane l sums
-        // column l & 31 over the Q / 2 rows of half l >> 5 and the halves meet with one exchange
-        __shared__ double jrow[kResolveWW][Q][29];
-        __shared__ double red[kResolveWW][28];
-        if (sub == 0) { // each term goes to LDS as it is formed (28 live doubles would cost 2 waves per SIMD)
-            double J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, b = 0.0;
-            if (valid) {
-                const int j = (unsigned)bj < (unsigned)m ? bj : 0;
-                if (j != jspec) { // the certificate found a nearer target
-                    q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
-                    n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
-                }
-                J[0] = py * n2 - pz * n1; // p x n, icp.hpp:105
-                J[1] = pz * n0 - px * n2;
-                J[2] = px * n1 - py * n0;
-                J[3] = n0;
-                J[4] = n1;
-                J[5] = n2;
-                const double e0 = q0 - px, e1 = q1 - py, e2 = q2 - pz;
-                b = (e0 * n0 + e1 * n1) + e2 * n2; // icp.hpp:116
-            }
-            double *row = jrow[wave][ql];
-            int o = 0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c = r; c < 6; ++c) row[o++] = J[r] * J[c];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) row[21 + r] = J[r] * b;
-            row[27] = b * b;
-        }
-        __builtin_amdgcn_wave_barrier();
-        {
-            const int c = lane & 31, h = lane >> 5;
-            double v = 0.0;
-            if (c < 28) {
-#pragma unroll
-                for (int r = 0; r < Q / 2; ++r) v += jrow[wave][h * (Q / 2) + r][c];
-            }
-            v += __shfl_xor(v, 32, 64);
-            if (lane < 28) red[wave][lane] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < 28) {
-            const int e = threadIdx.x;
-            double v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
-#pragma unroll
-            for (int w = 4; w < kResolveWW; ++w) v += red[w][e];
-            partials[(size_t)blockIdx.x * kSumsStride + e] = v;
-        }
-    }
+    resolve_finish<Q>(lane, wave, ql, sub, i, valid, bd, bj, px, py, pz, m, idx, d2out, counters, extra_slots, extra_splits,
+                      tgt_orig, nrm, partials, jspec, q0, q1, q2, n0, n1, n2);
 }
 
 // Variant with one query per QUARTER-wave (4 queries per wave): the 16 lanes of a quarter share

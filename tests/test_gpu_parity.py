@@ -986,6 +986,77 @@ print(json.dumps(out))
     assert all(v["iters"] >= 1 for v in legs["1"].values())
 
 
+def test_bounded_pass_gives_the_unbounded_pass_bits():
+    """nn_bounded.h: from its second pass on the ICP loop searches behind the rows' previous matches -- the coarse
+    pass lists the slots under each row's bound instead of keeping its minima, the resolve scans the listed slots
+    against the previous match as incumbent, no certificate.  Against ICPMI_NN_BOUNDED=0 (every pass k_nn_coarse<0> +
+    k_nn_resolve) the correspondences, hence the partial rows, pose, history and counts must agree BIT FOR BIT on
+    sources of more than 32,768 rows (below that the quarter-wave resolve runs, unbounded): uniform clouds, a raw
+    LiDAR-like frame pair, a cloud full of exact ties, a source with NaN / infinite rows, a start so far off that the
+    bounds span the whole target (every row takes the exhaustive search behind the split boxes), and two ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from lidar_slam_from_scratch_amd import capi, synth, dist as icpdist
+cases = {}
+s, t, _ = synth.c3_uniform(60000, seed=71, perm_seed=72)
+cases["uniform60k"] = (s, t, None, 8)
+cases["uniform40k_60k"] = (s[:40000], t, None, 6)
+cases["lidar_raw"] = (synth.lidar_frame(1, voxel=0), synth.lidar_frame(0, voxel=0), None, 6)
+rng = np.random.default_rng(5)
+grid = rng.integers(-20, 20, (70000, 3)).astype(np.float64)
+cases["ties"] = (grid[:40000] + 0.25, grid, None, 5)
+s2 = s.copy(); s2[17] = np.nan; s2[40001, 1] = np.inf
+cases["nan_rows"] = (s2, t, None, 5)
+T0 = synth.make_transform(np.array([0.3, -0.2, 0.25]), np.array([40.0, -25.0, 10.0]))
+cases["far_start"] = (s[:36000], t, T0, 4)
+out = {}
+ctx = capi.Context(device=0, profile=1)
+for name, (src, tgt, init, iters) in cases.items():
+    cfg = capi.Context.make_config(max_iterations=iters, tolerance=0.0, min_error=0.0, initial_transform=init)
+    ctx.reset_profile()
+    res, hist = ctx.align(src, tgt, cfg)
+    p = ctx.get_profile()
+    out[name] = {"T": [float.hex(v) for v in res.transformation[:]], "hist": [float.hex(v) for v in hist],
+                 "iters": res.num_iterations, "bounded": int(p["bounded_launches"]), "exhaustive": int(p["nn_fallback_queries"])}
+ctx.close()
+# two ranks (threads of this process, host-callback exchange), 45k rows each
+group = icpdist.LocalGroup(2)
+s, t, _ = synth.c3_uniform(90000, seed=81, perm_seed=82)
+def body(rank):
+    lo, hi = icpdist.shard_bounds(s.shape[0], 2, rank)
+    c = capi.Context(device=0)
+    group.attach(c, rank)
+    res, hist = c.align(s[lo:hi], t, capi.Context.make_config(max_iterations=4, tolerance=0.0, min_error=0.0))
+    c.comm_finalize(); c.close()
+    return [float.hex(v) for v in res.transformation[:]], [float.hex(v) for v in hist]
+r = group.run(body)
+assert r[0] == r[1]
+out["two_ranks"] = {"T": r[0][0], "hist": r[0][1]}
+print(json.dumps(out))
+''' % root
+    legs = {}
+    for knob in ("0", "1"):
+        env = dict(os.environ, ICPMI_NN_BOUNDED=knob)
+        r = subprocess.run([sys.executable, "-c", child], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        legs[knob] = json.loads(r.stdout.strip().splitlines()[-1])
+    for name, v in legs["1"].items():
+        if name == "two_ranks":
+            continue
+        assert legs["0"][name].pop("bounded") == 0 and v.pop("bounded") == v["iters"]   # every pass but the first (+ the post-loop pass)
+        ex0, ex1 = legs["0"][name].pop("exhaustive"), v.pop("exhaustive")
+        if name == "far_start":
+            assert ex1 > 30000                                                    # the exhaustive path did run
+    assert legs["0"] == legs["1"]
+
+
 def test_align_batch_is_the_sequential_calls(gpu_ctx):
     """icpmi_align_batch: the up-to-three verifications of one LoopClosureDetector::detect
     (loop_closure.hpp:94-123) side by side, each on a stream and workspace of its own.  Every result must
