@@ -411,7 +411,9 @@ int finish_transform_blocks(int n)
             const long x = strtol(e, nullptr, 10);
             if (x >= 1 && x <= 2048) return (int)x;
         }
-        return 32;
+        // (round 3: 128.  With the rows' bounds formed here too (RowBounds) the row part is worth spreading over more
+        // CUs than the repeated sums cost: 32 / 64 / 128 / 256 workgroups 22.1 / 18.2 / 16.5 / 16.5 us at 100k rows)
+        return 128;
     }();
     return std::max(1, std::min(cap, (n + kFinishThreads - 1) / kFinishThreads));
 }
@@ -575,7 +577,27 @@ bool nn_bounded_enabled()
     return on;
 }
 
-// `bounded`: d_idx holds the rows' matches of the previous pass (nn_bounded.h)
+// The per-row arrays of the bounded pass inside ctx->nn_lists (n rows)
+struct NnListRows {
+    double *ub;
+    unsigned *ent;
+    float *ubf, *sqf;
+    int *cnt;
+};
+constexpr size_t kNnListRowBytes = sizeof(double) + 2 * sizeof(float) + sizeof(int) + sizeof(unsigned) * kNnEntCap;
+NnListRows nn_list_rows(const icpmi_ctx *ctx, int n)
+{
+    NnListRows r;
+    r.ub = (double *)ctx->nn_lists.p;
+    r.ent = (unsigned *)(r.ub + n); // (8-byte aligned: read two words at a time)
+    r.ubf = (float *)(r.ent + (size_t)kNnEntCap * n);
+    r.sqf = r.ubf + n;
+    r.cnt = (int *)(r.sqf + n);
+    return r;
+}
+
+// `bounded`: d_idx holds the rows' matches of the previous pass and the kernel that moved the rows has left their bounds
+// in ctx->nn_lists (RowBounds, kernels.h; nn_bounded.h)
 int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx, double *d_d2,
                    const IcpState *st, const double *d_tgt = nullptr, const double *d_nrm = nullptr,
                    double *d_partials = nullptr, int pruned_pass = -1, bool bounded = false)
@@ -587,16 +609,12 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     unsigned long long *counters = (unsigned long long *)((char *)ctx->nn_misc.p + 128);
     Range range("icpmi:nn_search");
     StageTimer t(ctx, ST_NN);
-    if (bounded && pruned_pass < 0 && d_tgt && d_partials && !d_d2 && resolve_waves(n) == 0 && !coarse_half_units(ctx, n, splits) &&
-        nn_bounded_enabled()) {
-        constexpr size_t kRowBytes = sizeof(double) + 2 * sizeof(float) + sizeof(int) + sizeof(unsigned) * kNnEntCap;
-        if ((rc = reserve(ctx, ctx->nn_lists, kRowBytes * (size_t)n + 64))) return rc;
-        double *ub_row = (double *)ctx->nn_lists.p;
-        unsigned *ent_row = (unsigned *)(ub_row + n);            // (8-byte aligned: read two words at a time)
-        float *ubf_row = (float *)(ent_row + (size_t)kNnEntCap * n), *sqf_row = ubf_row + n;
-        int *cnt_row = (int *)(sqf_row + n);
-        hipLaunchKernelGGL(k_nn_bounds, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_qry, n, d_tgt, m, (const int *)d_idx,
-                           ub_row, ubf_row, sqf_row, cnt_row, st);
+    if (bounded) {
+        const NnListRows lr = nn_list_rows(ctx, n);
+        double *ub_row = lr.ub;
+        unsigned *ent_row = lr.ent;
+        float *ubf_row = lr.ubf, *sqf_row = lr.sqf;
+        int *cnt_row = lr.cnt;
         {
             StageTimer tc(ctx, ST_COARSE);
             hipLaunchKernelGGL((k_nn_coarse_bounded<kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
@@ -1124,6 +1142,16 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         src_perm = perm;
     }
 
+    // Bounded passes (nn_bounded.h): every kernel that moves the rows after a pass also leaves, per row, the exact distance
+    // to the target it was just matched with -- the bound the next pass searches behind.
+    const bool bounded_loop = sorted_rows_loop && nn_bounded_enabled();
+    RowBounds rb{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    if (bounded_loop) {
+        if ((rc = reserve(ctx, ctx->nn_lists, kNnListRowBytes * (size_t)n + 64))) return rc;
+        const NnListRows lr = nn_list_rows(ctx, n);
+        rb = RowBounds{d_tgt, idx, m, lr.ub, lr.ubf, lr.sqf, lr.cnt};
+    }
+
     // current_source = source * R0^T + t0^T (icp.hpp:174-176)
     if (n > 0 && !small) { // (an empty shard of a sharded run launches nothing over its rows; the small-cloud kernel moves them itself)
         StageTimer t(ctx, ST_TRANSFORM);
@@ -1172,7 +1200,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         const bool fuse_finish = !sharded && !pruned && n > 0 && !final_pass && fuse_finish_enabled();
         if (n > 0 && fused) {
             if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, st, d_tgt, nrm, partials,
-                                     pruned ? pass_no : -1, pass_no > 0 /* the rows' previous matches are in idx */))) return r2;
+                                     pruned ? pass_no : -1, bounded_loop && pass_no > 0 /* matches of the previous pass in idx, bounds in place */))) return r2;
             ++pass_no;
         } else if (n > 0) {
             if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, st))) return r2;
@@ -1191,7 +1219,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                     IcpState *other = st == ctx->d_state ? ctx->d_state + 1 : ctx->d_state;
                     hipLaunchKernelGGL(k_step_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
                                        (const double *)cur, cur, n, (const IcpState *)st, other, hist, progress, ticket,
-                                       ctx->n_ranks);
+                                       ctx->n_ranks, rb);
                     st = other;
                 } else {
                     hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, st, hist, final_pass, progress, ticket,
@@ -1201,7 +1229,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                 IcpState *other = st == ctx->d_state ? ctx->d_state + 1 : ctx->d_state;
                 hipLaunchKernelGGL(k_finish_step_transform, dim3(finish_transform_blocks(n)), dim3(kFinishThreads), 0, s,
                                    (const double *)partials, rblocks, n, (const double *)cur, cur, n,
-                                   (const IcpState *)st, other, hist, progress, ticket);
+                                   (const IcpState *)st, other, hist, progress, ticket, rb);
                 st = other;
             } else {
                 hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
@@ -1218,7 +1246,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                                    work_cnt + (pass_no & 1) /* the next pass's counter */);
             else
                 hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
-                                   cur, cur, n, st, 0, 1);
+                                   cur, cur, n, st, 0, 1, (const unsigned *)nullptr, rb);
         }
         return ICPMI_OK;
     };

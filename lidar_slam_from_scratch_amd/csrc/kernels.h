@@ -360,6 +360,83 @@ __global__ __launch_bounds__(64) void k_step(IcpState *st, double *history, int 
     __syncthreads();
     state_copy(st, &ls);
 }
+// ---- moving the rows (icp.hpp:174-176, 225-226), with the next pass's bounds ---------------------------------------
+// What the bounded correspondence search (nn_bounded.h) wants to know about a moved row before it starts: the exact squared
+// distance to the target the row was matched with one pass ago, and its fp32 images rounded up.  tgt == nullptr: nothing.
+struct RowBounds {
+    const double *tgt; // the target, caller's order
+    const int *idx;    // the rows' matches of the pass just finished
+    int m;
+    double *ub;        // [n] |moved row - tgt[idx]|^2, +Inf without a match
+    float *ubf, *sqf;  // [n] (float)ub and its square root, rounded up; NaN / 0 for a row with a non-finite coordinate
+    int *cnt;          // [n] the row's list length, cleared here for the coming coarse pass
+};
+// B rows of one thread (i0, i0 + stride, ...): every load that does not depend on the pose -- the rows, their previous
+// matches' indices, then those targets -- is requested by load(), which the fused kernels call BEFORE their serial step, so
+// that the round trips run under it; finish() moves the rows and stores the bounds.
+template <int B>
+struct RowBatch {
+    double x[B], y[B], z[B], tx[B], ty[B], tz[B];
+    bool have[B];
+    __device__ __forceinline__ void load(const double *in, const RowBounds &rb, int i0, int stride, int n,
+                                         const unsigned *__restrict__ perm = nullptr)
+    {
+        int j[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int i = i0 + b * stride;
+            x[b] = y[b] = z[b] = 0.0;
+            j[b] = -1;
+            if (i < n) {
+                const size_t ii = perm ? perm[i] : (unsigned)i;
+                x[b] = in[3 * ii], y[b] = in[3 * ii + 1], z[b] = in[3 * ii + 2];
+                if (rb.tgt) j[b] = rb.idx[i];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            have[b] = rb.tgt && (unsigned)j[b] < (unsigned)rb.m;
+            tx[b] = ty[b] = tz[b] = 0.0;
+            if (have[b]) tx[b] = rb.tgt[3 * (size_t)j[b]], ty[b] = rb.tgt[3 * (size_t)j[b] + 1], tz[b] = rb.tgt[3 * (size_t)j[b] + 2];
+        }
+    }
+    __device__ __forceinline__ void finish(double *out, const RowBounds &rb, int i0, int stride, int n, const double *T) const
+    {
+        const double r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3];
+        const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
+        const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int i = i0 + b * stride;
+            if (i >= n) continue;
+            const double px = ((x[b] * r00 + y[b] * r01) + z[b] * r02) + t0;
+            const double py = ((x[b] * r10 + y[b] * r11) + z[b] * r12) + t1;
+            const double pz = ((x[b] * r20 + y[b] * r21) + z[b] * r22) + t2;
+            out[3 * i] = px;
+            out[3 * i + 1] = py;
+            out[3 * i + 2] = pz;
+            if (rb.tgt) {
+                // A row with a NaN or infinite coordinate has no neighbour (kdtree.hpp:125): NaN, under which the coarse pass
+                // lists nothing.  No previous match (every target non-finite ...): +Inf, everything is listed.
+                double ub = __builtin_inf();
+                float ubf = __builtin_nanf(""), sqf = 0.f;
+                if (__builtin_isfinite(px) && __builtin_isfinite(py) && __builtin_isfinite(pz)) {
+                    if (have[b]) ub = sqdist(tx[b], ty[b], tz[b], px, py, pz);
+                    ubf = (float)ub;
+                    ubf = (double)ubf < ub ? __uint_as_float(__float_as_uint(ubf) + 1u) : ubf; // (ub >= 0; Inf stays Inf)
+                    sqf = __builtin_amdgcn_sqrtf(ubf);
+                    sqf = sqf < 3.0e38f ? __uint_as_float(__float_as_uint(sqf) + 2u) : sqf;   // (1 ulp of v_sqrt_f32 and one more)
+                }
+                rb.ub[i] = ub;
+                rb.ubf[i] = ubf;
+                rb.sqf[i] = sqf;
+                rb.cnt[i] = 0;
+            }
+        }
+    }
+};
+constexpr int kRowBatch = 4;
+
 
 // multi GPU, one launch fewer per iteration: k_step and k_transform in one kernel.  Every workgroup
 // repeats the (deterministic) step from the all-reduced sums on its own LDS copy of the state --
@@ -370,9 +447,12 @@ __global__ __launch_bounds__(64) void k_step(IcpState *st, double *history, int 
 // two (`sin` of one iteration is `sout` of the previous one).
 __global__ __launch_bounds__(256) void k_step_transform(const double *in, double *out, int n, const IcpState *sin,
                                                         IcpState *sout, double *history, int *progress, int ticket,
-                                                        int n_ranks)
+                                                        int n_ranks, const RowBounds rb)
 {
     __shared__ IcpState ls;
+    const int i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    RowBatch<kRowBatch> rows;
+    rows.load(in, rb, i0, stride, n);
     state_copy(&ls, sin);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -388,15 +468,9 @@ __global__ __launch_bounds__(256) void k_step_transform(const double *in, double
     __syncthreads();
     if (blockIdx.x == 0) state_copy(sout, &ls);
     if (ls.done) return; // the loop ended before or in this step: the source stays where it is (icp.hpp:210-217)
-    const double *T = ls.delta;
-    const double r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3];
-    const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
-    const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
-        out[3 * i] = ((x * r00 + y * r01) + z * r02) + t0;
-        out[3 * i + 1] = ((x * r10 + y * r11) + z * r12) + t1;
-        out[3 * i + 2] = ((x * r20 + y * r21) + z * r22) + t2;
+    for (int base = i0; base < n; base += kRowBatch * stride) {
+        if (base != i0) rows.load(in, rb, base, stride, n);
+        rows.finish(out, rb, base, stride, n, ls.delta);
     }
 }
 
@@ -408,15 +482,15 @@ __global__ __launch_bounds__(256) void k_step_transform(const double *in, double
 // into the other state buffer.  No workgroup waits for another one.
 __global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform(
     const double *__restrict__ partials, int nblocks, int n_local, const double *in, double *out, int n,
-    const IcpState *sin, IcpState *sout, double *history, int *progress, int ticket)
+    const IcpState *sin, IcpState *sout, double *history, int *progress, int ticket, const RowBounds rb)
 {
     __shared__ IcpState ls, sums; // `sums`: only its sums[] are used
     // The kernel is a chain of memory round trips, so everything that does not depend on the state
-    // is requested first: this thread's first point, and the partial rows (summed whether or not
-    // the loop has ended; the sums are taken over only if it has not, like k_finish_step).
-    const int i0 = blockIdx.x * kFinishThreads + threadIdx.x;
-    double x = 0.0, y = 0.0, z = 0.0;
-    if (i0 < n) x = in[3 * i0], y = in[3 * i0 + 1], z = in[3 * i0 + 2];
+    // is requested first: this thread's first rows (with their previous matches), and the partial rows (summed whether
+    // or not the loop has ended; the sums are taken over only if it has not, like k_finish_step).
+    const int i0 = blockIdx.x * kFinishThreads + threadIdx.x, stride = gridDim.x * kFinishThreads;
+    RowBatch<kRowBatch> rows;
+    rows.load(in, rb, i0, stride, n);
     state_copy(&ls, sin);
     finish_sums(partials, nblocks, n_local, &sums);
     __syncthreads();
@@ -429,15 +503,9 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform(
     __syncthreads();
     if (blockIdx.x == 0) state_copy(sout, &ls);
     if (ls.done) return; // the loop ended before or in this step: the source stays where it is (icp.hpp:210-217)
-    const double *T = ls.delta;
-    const double r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3];
-    const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
-    const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
-    for (int i = i0; i < n; i += gridDim.x * kFinishThreads) {
-        if (i != i0) x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
-        out[3 * i] = ((x * r00 + y * r01) + z * r02) + t0;
-        out[3 * i + 1] = ((x * r10 + y * r11) + z * r12) + t1;
-        out[3 * i + 2] = ((x * r20 + y * r21) + z * r22) + t2;
+    for (int base = i0; base < n; base += kRowBatch * stride) {
+        if (base != i0) rows.load(in, rb, base, stride, n);
+        rows.finish(out, rb, base, stride, n, ls.delta);
     }
 }
 
@@ -459,19 +527,16 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_solve(const double *_
 // perm (may be null): out row i is made from in row perm[i] (the ICP loop takes its source rows in Morton order)
 __global__ __launch_bounds__(256) void k_transform(const double *in, double *out, int n,
                                                    const IcpState *__restrict__ st, int which,
-                                                   int honour_done, const unsigned *__restrict__ perm = nullptr)
+                                                   int honour_done, const unsigned *__restrict__ perm = nullptr,
+                                                   const RowBounds rb = RowBounds{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr})
 {
     if (honour_done && st->done) return;
     const double *T = which ? st->total : st->delta;
-    const double r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3];
-    const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
-    const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const size_t ii = perm ? perm[i] : (unsigned)i;
-        const double x = in[3 * ii], y = in[3 * ii + 1], z = in[3 * ii + 2];
-        out[3 * i] = ((x * r00 + y * r01) + z * r02) + t0;
-        out[3 * i + 1] = ((x * r10 + y * r11) + z * r12) + t1;
-        out[3 * i + 2] = ((x * r20 + y * r21) + z * r22) + t2;
+    const int i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    RowBatch<kRowBatch> rows;
+    for (int base = i0; base < n; base += kRowBatch * stride) {
+        rows.load(in, rb, base, stride, n, perm);
+        rows.finish(out, rb, base, stride, n, T);
     }
 }
 

@@ -4,7 +4,9 @@
 // Every row of the moved source still knows the target it was matched with one pass ago.  That target is a real
 // target, so its exact distance to the moved row, ub, bounds the new nearest-neighbour distance from above BEFORE
 // anything is searched -- and with the bound in hand the coarse pass no longer has to keep its minima:
-//   k_nn_bounds          ub(row) = |row - target[previous match]|^2 exactly (and its fp32 images, rounded up)
+//   RowBounds (kernels.h) ub(row) = |row - target[previous match]|^2 exactly (and its fp32 images, rounded up), left by
+//                        the kernel that moves the rows after a pass (k_finish_step_transform, k_step_transform,
+//                        k_transform): the previous matches' coordinates are fetched under that kernel's serial step
 //   k_nn_coarse_bounded  the all-pairs pass with the MODE 3 epilogue: the columns (slots of 64 sorted targets) whose
 //                        minimum is <= tau_s(ub(row)), the bound on the coarse value of any target of split s within
 //                        ub (nn_mfma.h), are listed per row, 16 columns to a word -- one word per row, rarely two,
@@ -28,35 +30,6 @@
 namespace icpmi {
 
 constexpr int kNnSlotCap = 16; // listed slots scanned per row
-
-__global__ __launch_bounds__(256) void k_nn_bounds(const double *__restrict__ cur, int n, const double *__restrict__ tgt_orig,
-                                                   int m, const int *__restrict__ idx_prev,
-                                                   double *__restrict__ ub_row, float *__restrict__ ubf_row,
-                                                   float *__restrict__ sqf_row, int *__restrict__ cnt_row,
-                                                   const IcpState *__restrict__ st)
-{
-    if (st && st->done) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const double px = cur[3 * i], py = cur[3 * i + 1], pz = cur[3 * i + 2];
-    const int j = idx_prev[i];
-    // fp32 images for the coarse pass, rounded up.  A row with a NaN or infinite coordinate has no neighbour
-    // (kdtree.hpp:125): NaN, under which nothing is listed.  No previous match (every target non-finite ...): +Inf,
-    // everything is listed.
-    double ub = __builtin_inf();
-    float ubf = __builtin_nanf(""), sqf = 0.f;
-    if (finite3(px, py, pz)) {
-        if ((unsigned)j < (unsigned)m) ub = sqdist(tgt_orig[3 * j], tgt_orig[3 * j + 1], tgt_orig[3 * j + 2], px, py, pz);
-        ubf = (float)ub;
-        ubf = (double)ubf < ub ? __uint_as_float(__float_as_uint(ubf) + 1u) : ubf; // (ub >= 0; Inf stays Inf)
-        sqf = __builtin_amdgcn_sqrtf(ubf);
-        sqf = sqf < 3.0e38f ? __uint_as_float(__float_as_uint(sqf) + 2u) : sqf;   // (1 ulp of v_sqrt_f32 and one more)
-    }
-    ub_row[i] = ub;
-    ubf_row[i] = ubf;
-    sqf_row[i] = sqf;
-    cnt_row[i] = 0;
-}
 
 // Q = 16 queries per wave, the lane layout, workgroup shape and sums of k_nn_resolve<16>.
 __global__ __launch_bounds__(64 * kResolveWW) void k_nn_resolve_bounded(
