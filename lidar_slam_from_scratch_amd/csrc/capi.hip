@@ -617,18 +617,29 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
         int *cnt_row = lr.cnt;
         {
             StageTimer tc(ctx, ST_COARSE);
-            hipLaunchKernelGGL((k_nn_coarse_bounded<kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
-                               dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames,
-                               KnnLists{ubf_row, sqf_row, cnt_row, ent_row, kNnEntCap}, st);
+            const KnnLists kl{ubf_row, sqf_row, cnt_row, ent_row, kNnEntCap};
+            if (coarse_half_units(ctx, n, splits)) {
+                constexpr int per = kCoarseQueries / kCoarseQT; // queries per workgroup with one tile per wave
+                hipLaunchKernelGGL((k_nn_coarse_bounded<1, kCoarseWaves>), dim3((n + per - 1) / per, splits), dim3(kCoarseThreads), 0,
+                                   ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames, kl, st);
+            } else
+                hipLaunchKernelGGL((k_nn_coarse_bounded<kCoarseQT, kCoarseWaves>), dim3((n + kCoarseQueries - 1) / kCoarseQueries, splits),
+                                   dim3(kCoarseThreads), 0, ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames, kl, st);
             ctx->prof.nn_coarse_blocks += (int64_t)((n + kCoarseQueries - 1) / kCoarseQueries) * splits;
         }
-        hipLaunchKernelGGL(k_nn_resolve_bounded, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, d_qry, n,
-                           (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, splits, frames, (const double *)ub_row,
-                           (const int *)cnt_row, (const unsigned *)ent_row, d_idx,
-                           // (the statistics are two words every wave with something to report adds to: with one row in a
-                           // hundred listing a second slot that is most waves of a pass, and the same-address atomics were
-                           // 25 of the kernel's 55 us -- counted when a profile is asked for only)
-                           ctx->opt.profile ? counters : (unsigned long long *)nullptr, d_tgt, d_nrm, d_partials, st);
+        // (the statistics: with one row in a hundred listing a second slot, most waves of a pass have something to add to the
+        // same two words, and per wave those atomics were 25 of the kernel's 55 us -- they leave per workgroup now, and
+        // only when the stage profile (level 2) is asked for)
+#define ICPMI_BOUNDED_ARGS                                                                                                        \
+    d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, splits, frames, (const double *)ub_row, (const int *)cnt_row, \
+        (const unsigned *)ent_row, d_idx, ctx->opt.profile >= 2 ? counters : (unsigned long long *)nullptr, d_tgt, d_nrm, d_partials, st
+        switch (resolve_waves(n)) {
+        case 0: hipLaunchKernelGGL(k_nn_resolve_bounded, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
+        case 4: hipLaunchKernelGGL(k_nn_resolve4_bounded<4>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
+        case 8: hipLaunchKernelGGL(k_nn_resolve4_bounded<8>, dim3(resolve_blocks(n)), dim3(512), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
+        default: hipLaunchKernelGGL(k_nn_resolve4_bounded<16>, dim3(resolve_blocks(n)), dim3(1024), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
+        }
+#undef ICPMI_BOUNDED_ARGS
         ctx->prof.nn_pairs += (double)n * (double)m;
         ctx->prof.bounded_launches += 1;
         HIP_TRY(ctx, hipGetLastError());
@@ -1110,7 +1121,11 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // tile of 32 neighbouring rows has its matches in one or two splits, so the bounded pass's epilogue (nn_bounded.h)
     // finds nothing to list in the other 47 and leaves by its short path: with rows in the caller's order half of all
     // (tile, split) pairs listed something (k_nn_coarse_bounded 305 -> 295 us on C3, k_nn_resolve_bounded 29 -> 28).
-    const bool sorted_rows_loop = fused && !pruned && !small && n > 0 && resolve_waves(n) == 0 && !coarse_half_units(ctx, n, splits);
+    // (from 4,096 rows: below, the Morton sort of the rows costs a call more than its passes gain)
+    // (not where ICPMI_SMALL=0 puts the general kernels in the small-cloud kernel's place: there they keep its order of rows,
+    // hence its bits)
+    const bool small_regime = !sharded_run && n <= small_max_queries() && ctx->nn_splits <= kSmallMaxSplits;
+    const bool sorted_rows_loop = fused && !pruned && !small && !small_regime && n >= 4096 && resolve_waves(n) != -32;
     size_t sort_bytes = 0;
     if (pruned || sorted_rows_loop) {
         HIP_TRY(ctx, sort_pairs_u32(nullptr, &sort_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned)n, s));

@@ -207,4 +207,135 @@ __global__ __launch_bounds__(64 * kResolveWW) void k_nn_resolve_bounded(
                       tgt_orig, nrm, partials, -1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);
 }
 
+// One query per QUARTER-wave: the lane layout, workgroup shape and sums of k_nn_resolve4<WAVES> (sources of at most
+// 32,768 rows: a wave's chain of round trips is what counts there, and this one has a quarter of the rounds).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4_bounded(
+    const double *__restrict__ qry, int n, const double *__restrict__ sorted, const unsigned *__restrict__ perm, int m, int ms,
+    int splits, const SplitFrame *__restrict__ frames, const double *__restrict__ ub_row, const int *__restrict__ cnt_row,
+    const unsigned *__restrict__ ent_row, int *__restrict__ idx /* in: previous match, out: this pass's */,
+    unsigned long long *__restrict__ counters, const double *__restrict__ tgt_orig, const double *__restrict__ nrm,
+    double *__restrict__ partials, const IcpState *__restrict__ st)
+{
+    __shared__ int flist[WAVES][4][kNnSlotCap];
+    if (st && st->done) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 15, quarter = lane >> 4;
+    const int qbase = (blockIdx.x * WAVES + wave) * 4;
+    const int i = qbase + quarter; // waves past the end run on a clamped query and write nothing
+    const bool valid = i < n;
+    const int ic = valid ? i : n - 1;
+    const double px = qry[3 * ic], py = qry[3 * ic + 1], pz = qry[3 * ic + 2];
+    const bool look = valid && finite3(px, py, pz);
+    const double kMax = 1.7976931348623157e308;
+
+    // the incumbent: the previous match at its exact distance
+    const int jprev = idx[ic];
+    double bd = ub_row[ic];
+    int bj = (unsigned)jprev < (unsigned)m ? jprev : 0x7fffffff;
+    if (!look) bj = 0x7fffffff;
+    if (bj == 0x7fffffff) bd = kMax;
+
+    // the row's list: lane ql < 8 of the quarter holds word ql; the first listed slot is the lowest bit of word 0
+    const int cnt = cnt_row[ic];
+    const unsigned w = (look && ql < cnt && ql < kNnEntCap) ? ent_row[(size_t)ic * kNnEntCap + ql] : 0u;
+    const int mine = __popc(w & 0xFFFFu);
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < kNnEntCap; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        incl += ql >= off ? o : 0;
+    }
+    const int nsl = __shfl(incl, quarter * 16 + kNnEntCap - 1, 64);
+    auto word_base = [](unsigned word) -> int { return (int)(word >> 17) * kCols + (int)((word >> 16) & 1u) * 16; };
+    const unsigned w0 = (unsigned)__shfl((int)w, quarter * 16, 64);
+    const int first_slot = word_base(w0) + ((w0 & 0xFFFFu) ? __ffs((int)(w0 & 0xFFFFu)) - 1 : 0);
+    const bool over = look && (cnt > kNnEntCap || nsl > kNnSlotCap);
+    const int ns = over ? 0 : nsl;
+
+    double d = kMax;
+    int jo = 0x7fffffff;
+    auto scan_slot = [&](const int slot, const bool act) {
+        const int j0 = (slot / kCols) * kSplitTargets + (slot % kCols) * kSlotTargets + ql;
+#pragma unroll
+        for (int o = 0; o < kSlotTargets / 16; ++o) {
+            const int jj = j0 + 16 * o; // (no clamp for the coordinates: see k_nn_resolve_bounded)
+            const int oj = (int)perm[jj < m ? jj : m - 1];
+            const double dd = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), px, py, pz);
+            if (act && jj < m && (dd < d || (dd == d && oj < jo))) {
+                d = dd;
+                jo = oj;
+            }
+        }
+    };
+    scan_slot(first_slot, ns > 0);
+    if (__ballot(ns > 1) != 0ull) { // further slots: through LDS, lane ql expands its word
+        int pos = incl - mine;
+        unsigned msk = w & 0xFFFFu;
+        const int base = word_base(w);
+        while (msk) {
+            if (pos < kNnSlotCap) flist[wave][quarter][pos] = base + __ffs((int)msk) - 1;
+            ++pos;
+            msk &= msk - 1u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int t = 1; __ballot(t < ns) != 0ull; ++t) scan_slot(t < ns ? flist[wave][quarter][t] : 0, t < ns);
+    }
+#pragma unroll
+    for (int x = 1; x < 16; x <<= 1) {
+        const double od = __shfl_xor(d, x, 64);
+        const int oj = __shfl_xor(jo, x, 64);
+        if (od < d || (od == d && oj < jo)) {
+            d = od;
+            jo = oj;
+        }
+    }
+    if (look && (d < bd || (d == bd && jo < bj))) {
+        bd = d;
+        bj = jo;
+    }
+
+    // rows whose list did not fit: exhaustive search behind the split and slot boxes (see k_nn_resolve_bounded)
+    unsigned extra_splits = 0;
+    unsigned long long pend = __ballot(over && ql == 0);
+    while (pend) { // rare; wave-uniform loop
+        const int L = __ffsll((long long)pend) - 1;
+        pend &= pend - 1;
+        const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
+        double qd = __shfl(bd, L, 64);
+        int qj = __shfl(bj, L, 64);
+        for (int s0 = 0; s0 < splits; s0 += 64) {
+            bool keep = false;
+            if (s0 + lane < splits) {
+                const SplitFrame &f = frames[s0 + lane];
+                double lb = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double q = px_sel(a, qx, qy, qz);
+                    const double g1 = f.lo[a] - q, g2 = q - f.hi[a];
+                    const double g = g1 > g2 ? (g1 > 0.0 ? g1 : 0.0) : (g2 > 0.0 ? g2 : 0.0);
+                    lb += g * g;
+                }
+                keep = !(lb * (1.0 - 1e-9) > qd);
+            }
+            unsigned long long smask = __ballot(keep);
+            while (smask) {
+                const int sL = s0 + __ffsll((long long)smask) - 1;
+                smask &= smask - 1;
+                scan_split<ICPMI_RESOLVE4_SCANBATCH>(sorted, perm, m, ms, reinterpret_cast<const double *>(frames + splits), sL, qx, qy,
+                                                     qz, qd, lane, qd, qj);
+            }
+        }
+        if ((lane >> 4) == (L >> 4)) {
+            bd = qd;
+            bj = qj;
+        }
+        if (lane == L) ++extra_splits;
+    }
+
+    const unsigned extra_slots = (ql == 0 && look && !over && nsl > 1) ? (unsigned)(nsl - 1) : 0u;
+    resolve4_finish<WAVES>(lane, wave, ql, quarter, i, valid, bd, bj, px, py, pz, m, idx, nullptr, counters, extra_slots, extra_splits,
+                           tgt_orig, nrm, partials, -1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);
+}
+
 } // namespace icpmi

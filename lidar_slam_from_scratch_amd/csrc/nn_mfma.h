@@ -1281,15 +1281,23 @@ __device__ __forceinline__ void resolve_finish(const int lane, const int wave, c
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
         if (d2out) d2out[i] = bd;
     }
+    // statistics: a wave's counts; with the normal-equation terms below they meet in LDS first and leave as ONE pair of
+    // atomics per workgroup (thousands of waves adding to the same two words were a third of the bounded resolve's time)
+    __shared__ unsigned wave_cnt[kResolveWW][2];
     if (counters) {
         unsigned es = extra_slots, ef = extra_splits;
         for (int off = 32; off > 0; off >>= 1) {
             es += __shfl_down(es, off, 64);
             ef += __shfl_down(ef, off, 64);
         }
-        if (lane == 0 && (es | ef)) {
-            atomicAdd(&counters[0], (unsigned long long)es);
-            atomicAdd(&counters[1], (unsigned long long)ef);
+        if (lane == 0) {
+            if (partials) {
+                wave_cnt[wave][0] = es;
+                wave_cnt[wave][1] = ef;
+            } else if (es | ef) {
+                atomicAdd(&counters[0], (unsigned long long)es);
+                atomicAdd(&counters[1], (unsigned long long)ef);
+            }
         }
     }
     // fused residual + normal equations (what k_reduce does, icp.hpp:99-120,198-206): the Q
@@ -1339,6 +1347,12 @@ __device__ __forceinline__ void resolve_finish(const int lane, const int wave, c
             if (lane < 28) red[wave][lane] = v;
         }
         __syncthreads();
+        if (counters && threadIdx.x == 32) {
+            unsigned es = 0, ef = 0;
+            for (int w = 0; w < kResolveWW; ++w) es += wave_cnt[w][0], ef += wave_cnt[w][1];
+            if (es) atomicAdd(&counters[0], (unsigned long long)es);
+            if (ef) atomicAdd(&counters[1], (unsigned long long)ef);
+        }
         if (threadIdx.x < 28) {
             const int e = threadIdx.x;
             double v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
@@ -1516,6 +1530,99 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
                       tgt_orig, nrm, partials, jspec, q0, q1, q2, n0, n1, n2);
 }
 
+// The end of the quarter-wave resolve kernels (k_nn_resolve4, k_nn_resolve4_bounded): results out, counters, and the fused
+// residual + normal-equation terms.  (jspec, q*, n*): the matched target and normal gathered ahead for target `jspec`
+// (< 0: nothing was gathered).
+template <int WAVES>
+__device__ __forceinline__ void resolve4_finish(const int lane, const int wave, const int ql, const int quarter, const int i,
+                                                const bool valid, const double bd, const int bj, const double px,
+                                                const double py, const double pz, const int m, int *__restrict__ idx,
+                                                double *__restrict__ d2out, unsigned long long *__restrict__ counters,
+                                                const unsigned extra_slots, const unsigned extra_splits,
+                                                const double *__restrict__ tgt_orig, const double *__restrict__ nrm,
+                                                double *__restrict__ partials, const int jspec, double q0, double q1,
+                                                double q2, double n0, double n1, double n2)
+{
+    if (valid && ql == 0) {
+        idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
+        if (d2out) d2out[i] = bd;
+    }
+    // statistics: a wave's counts; with the normal-equation terms below they meet in LDS first and leave as ONE pair of
+    // atomics per workgroup (thousands of waves adding to the same two words were a third of the bounded resolve's time)
+    __shared__ unsigned wave_cnt[WAVES][2];
+    if (counters) {
+        unsigned es = extra_slots, ef = extra_splits;
+        for (int off = 32; off > 0; off >>= 1) {
+            es += __shfl_down(es, off, 64);
+            ef += __shfl_down(ef, off, 64);
+        }
+        if (lane == 0) {
+            if (partials) {
+                wave_cnt[wave][0] = es;
+                wave_cnt[wave][1] = ef;
+            } else if (es | ef) {
+                atomicAdd(&counters[0], (unsigned long long)es);
+                atomicAdd(&counters[1], (unsigned long long)ef);
+            }
+        }
+    }
+    // fused residual + normal equations (icp.hpp:99-120,198-206): the 4 owners of a wave (lane 0
+    // of each quarter) form their J row and b; rows -> LDS, each wave sums its four by column,
+    // the waves' sums meet in LDS in wave order: one partial row per workgroup
+    if (partials) {
+        __shared__ double jrow[WAVES * 4][29];
+        __shared__ double red[WAVES][28];
+        if (ql == 0) {
+            double acc[28];
+#pragma unroll
+            for (int e = 0; e < 28; ++e) acc[e] = 0.0;
+            if (valid) {
+                const int j = (unsigned)bj < (unsigned)m ? bj : 0;
+                if (j != jspec) { // the certificate found a nearer target
+                    q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
+                    n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
+                }
+                double J[6];
+                J[0] = py * n2 - pz * n1; // p x n, icp.hpp:105
+                J[1] = pz * n0 - px * n2;
+                J[2] = px * n1 - py * n0;
+                J[3] = n0;
+                J[4] = n1;
+                J[5] = n2;
+                const double e0 = q0 - px, e1 = q1 - py, e2 = q2 - pz;
+                const double b = (e0 * n0 + e1 * n1) + e2 * n2; // icp.hpp:116
+                int o = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = r; c < 6; ++c) acc[o++] = J[r] * J[c];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) acc[21 + r] = J[r] * b;
+                acc[27] = b * b;
+            }
+#pragma unroll
+            for (int e = 0; e < 28; ++e) jrow[wave * 4 + quarter][e] = acc[e];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 28)
+            red[wave][lane] = ((jrow[wave * 4][lane] + jrow[wave * 4 + 1][lane]) + jrow[wave * 4 + 2][lane]) + jrow[wave * 4 + 3][lane];
+        __syncthreads();
+        if (counters && threadIdx.x == 32) {
+            unsigned es = 0, ef = 0;
+            for (int w = 0; w < WAVES; ++w) es += wave_cnt[w][0], ef += wave_cnt[w][1];
+            if (es) atomicAdd(&counters[0], (unsigned long long)es);
+            if (ef) atomicAdd(&counters[1], (unsigned long long)ef);
+        }
+        if (threadIdx.x < 28) {
+            const int e = threadIdx.x;
+            double v = red[0][e];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) v += red[w][e];
+            partials[(size_t)blockIdx.x * kSumsStride + e] = v;
+        }
+    }
+}
+
 // Variant with one query per QUARTER-wave (4 queries per wave): the 16 lanes of a quarter share
 // the splits of their query (lane ql takes list entries ql, ql+16, ...) and scan its winning
 // slot together, in one round.  Same result as k_nn_resolve; a wave's chain of dependent memory
@@ -1628,70 +1735,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
     unsigned extra_slots = 0, extra_splits = 0;
     resolve_certify<16, 4, KEEP4, ICPMI_RESOLVE4_SCANBATCH>(pv, lane, ql, valid, ic, n, px, py, pz, coarse, splits, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                         bd, bj, extra_slots, extra_splits);
-    if (valid && ql == 0) {
-        idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
-        if (d2out) d2out[i] = bd;
-    }
-    if (counters) {
-        unsigned es = extra_slots, ef = extra_splits;
-        for (int off = 32; off > 0; off >>= 1) {
-            es += __shfl_down(es, off, 64);
-            ef += __shfl_down(ef, off, 64);
-        }
-        if (lane == 0 && (es | ef)) {
-            atomicAdd(&counters[0], (unsigned long long)es);
-            atomicAdd(&counters[1], (unsigned long long)ef);
-        }
-    }
-    // fused residual + normal equations (icp.hpp:99-120,198-206): the 4 owners of a wave (lane 0
-    // of each quarter) form their J row and b; rows -> LDS, each wave sums its four by column,
-    // the waves' sums meet in LDS in wave order: one partial row per workgroup
-    if (partials) {
-        __shared__ double jrow[WAVES * 4][29];
-        __shared__ double red[WAVES][28];
-        if (ql == 0) {
-            double acc[28];
-#pragma unroll
-            for (int e = 0; e < 28; ++e) acc[e] = 0.0;
-            if (valid) {
-                const int j = (unsigned)bj < (unsigned)m ? bj : 0;
-                if (j != jspec) { // the certificate found a nearer target
-                    q0 = tgt_orig[3 * j], q1 = tgt_orig[3 * j + 1], q2 = tgt_orig[3 * j + 2];
-                    n0 = nrm[3 * j], n1 = nrm[3 * j + 1], n2 = nrm[3 * j + 2];
-                }
-                double J[6];
-                J[0] = py * n2 - pz * n1; // p x n, icp.hpp:105
-                J[1] = pz * n0 - px * n2;
-                J[2] = px * n1 - py * n0;
-                J[3] = n0;
-                J[4] = n1;
-                J[5] = n2;
-                const double e0 = q0 - px, e1 = q1 - py, e2 = q2 - pz;
-                const double b = (e0 * n0 + e1 * n1) + e2 * n2; // icp.hpp:116
-                int o = 0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int c = r; c < 6; ++c) acc[o++] = J[r] * J[c];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) acc[21 + r] = J[r] * b;
-                acc[27] = b * b;
-            }
-#pragma unroll
-            for (int e = 0; e < 28; ++e) jrow[wave * 4 + quarter][e] = acc[e];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 28)
-            red[wave][lane] = ((jrow[wave * 4][lane] + jrow[wave * 4 + 1][lane]) + jrow[wave * 4 + 2][lane]) + jrow[wave * 4 + 3][lane];
-        __syncthreads();
-        if (threadIdx.x < 28) {
-            const int e = threadIdx.x;
-            double v = red[0][e];
-#pragma unroll
-            for (int w = 1; w < WAVES; ++w) v += red[w][e];
-            partials[(size_t)blockIdx.x * kSumsStride + e] = v;
-        }
-    }
+    resolve4_finish<WAVES>(lane, wave, ql, quarter, i, valid, bd, bj, px, py, pz, m, idx, d2out, counters, extra_slots, extra_splits,
+                           tgt_orig, nrm, partials, jspec, q0, q1, q2, n0, n1, n2);
 }
 
 // ---- k-NN on the same coarse pass ---------------------------------------------------------------

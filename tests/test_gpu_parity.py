@@ -990,8 +990,9 @@ def test_bounded_pass_gives_the_unbounded_pass_bits():
     """nn_bounded.h: from its second pass on the ICP loop searches behind the rows' previous matches -- the coarse
     pass lists the slots under each row's bound instead of keeping its minima, the resolve scans the listed slots
     against the previous match as incumbent, no certificate.  Against ICPMI_NN_BOUNDED=0 (every pass k_nn_coarse<0> +
-    k_nn_resolve) the correspondences, hence the partial rows, pose, history and counts must agree BIT FOR BIT on
-    sources of more than 32,768 rows (below that the quarter-wave resolve runs, unbounded): uniform clouds, a raw
+    k_nn_resolve / k_nn_resolve4) the correspondences, hence the partial rows, pose, history and counts must agree BIT
+    FOR BIT, for both resolve layouts (16 rows per wave above 32,768 rows, one per quarter-wave below) and both coarse
+    unit sizes: uniform clouds, a raw
     LiDAR-like frame pair, a cloud full of exact ties, a source with NaN / infinite rows, a start so far off that the
     bounds span the whole target (every row takes the exhaustive search behind the split boxes), and two ranks."""
     import json
@@ -1007,6 +1008,8 @@ cases = {}
 s, t, _ = synth.c3_uniform(60000, seed=71, perm_seed=72)
 cases["uniform60k"] = (s, t, None, 8)
 cases["uniform40k_60k"] = (s[:40000], t, None, 6)
+cases["shard12k_60k"] = (s[:12500], t, None, 6)          # quarter-wave resolve (k_nn_resolve4_bounded<8>)
+cases["few_units_5k_40k"] = (s[:5000], t[:40000], None, 6)  # 256-query coarse units
 cases["lidar_raw"] = (synth.lidar_frame(1, voxel=0), synth.lidar_frame(0, voxel=0), None, 6)
 rng = np.random.default_rng(5)
 grid = rng.integers(-20, 20, (70000, 3)).astype(np.float64)
@@ -1016,7 +1019,7 @@ cases["nan_rows"] = (s2, t, None, 5)
 T0 = synth.make_transform(np.array([0.3, -0.2, 0.25]), np.array([40.0, -25.0, 10.0]))
 cases["far_start"] = (s[:36000], t, T0, 4)
 out = {}
-ctx = capi.Context(device=0, profile=1)
+ctx = capi.Context(device=0, profile=2)   # (2: the bounded passes report their statistics too)
 for name, (src, tgt, init, iters) in cases.items():
     cfg = capi.Context.make_config(max_iterations=iters, tolerance=0.0, min_error=0.0, initial_transform=init)
     ctx.reset_profile()
