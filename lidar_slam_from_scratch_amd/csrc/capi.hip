@@ -775,7 +775,7 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
         }();
         // all-pairs engine, rows in the target's Morton order: bound first, lists instead of minima (knn_lists.h)
         const bool lists = by_sorted_row && !ctx->nn_pruned;
-        constexpr long kListRowBytes = sizeof(double) + sizeof(float) + sizeof(int) + sizeof(unsigned) * kKnnEntCap;
+        constexpr long kListRowBytes = sizeof(double) + 2 * sizeof(float) + sizeof(int) + sizeof(unsigned) * kKnnEntCap;
         const long budget = lists ? (1l << 30) : by_sorted_row ? (4l << 30) : knn_budget;
         long chunk = (budget / (lists ? kListRowBytes : (long)nslots * 2)) / kCoarseQueries * kCoarseQueries; // 2 bytes per slot minimum (bf16)
         chunk = std::max<long>(kCoarseQueries, std::min<long>(chunk, ((long)rows + kCoarseQueries - 1) / kCoarseQueries * kCoarseQueries));
@@ -801,12 +801,12 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
             const int nblk = (nq + kCoarseQueries - 1) / kCoarseQueries;
             if (lists) {
                 double *t_row = (double *)ctx->slotmin.p;
-                float *thr_row = (float *)(t_row + chunk);
-                int *cnt_row = (int *)(thr_row + chunk);
+                float *tf_row = (float *)(t_row + chunk), *sqf_row = tf_row + chunk;
+                int *cnt_row = (int *)(sqf_row + chunk);
                 unsigned *ent_row = (unsigned *)(cnt_row + chunk);
-                const KnnLists kl{thr_row, nullptr, cnt_row, ent_row, kKnnEntCap};
+                const KnnLists kl{tf_row, sqf_row, cnt_row, ent_row, kKnnEntCap};
                 hipLaunchKernelGGL(k_knn_prebound, dim3((nq + kPreRows - 1) / kPreRows), dim3(256), 0, s, sorted, m, ctx->nn_ms, k, (int)c0, nq,
-                                   (const NnFrame *)ctx->nn_misc.p, t_row, thr_row, cnt_row);
+                                   t_row, tf_row, sqf_row, cnt_row);
                 if (coarse_half_units(ctx, nq, splits)) {
                     constexpr int per = kCoarseQueries / kCoarseQT;
                     hipLaunchKernelGGL((k_nn_coarse_rows<1, kCoarseWaves>), dim3((nq + per - 1) / per, splits), dim3(kCoarseThreads), 0,

@@ -7,16 +7,15 @@
 // instructions per row, most of them loading, bounding and filtering those minima.  Here the rows are
 // taken in the target's MORTON order, where a row's neighbours in the array are neighbours in space:
 //   k_knn_prebound      T(row) = the k-th smallest of 32 disjoint groups of exact distances to the 256 sorted
-//                       positions around the row: k different targets within T, hence d_k <= T; and
-//                       thr(row) = the bound on the coarse value of any target within T that holds for EVERY
-//                       split (all_splits_tau, nn_mfma.h)
+//                       positions around the row: k different targets within T, hence d_k <= T
 //   k_nn_coarse_rows    the all-pairs pass, MODE 2 epilogue: per (row, split, half) one word with the columns
-//                       whose minimum is <= thr(row), appended to the row's list -- a few words per row
-//                       (144 B per row with bound and count, whatever the target's size)
+//                       whose minimum is <= tau_s(T(row)), the bound on the coarse value of any target of split s
+//                       within T (nn_mfma.h), appended to the row's list -- a few words per row (148 B per row with
+//                       bound and count, whatever the target's size)
 //   k_knn_resolve_lists exact fp64 scan of the listed slots, candidates with distance <= T ranked by
 //                       (distance, original index), the k smallest written closest first
 // Every true k-neighbour t of a row has exact distance <= d_k <= T, so its coarse value, and with it its
-// slot's minimum, is <= thr(row): its slot is listed, t is scanned exactly and ranked.  The result is the
+// slot's minimum, is <= tau_s(T): its slot is listed, t is scanned exactly and ranked.  The result is the
 // exact list whatever the bound was -- bit-identical to round 2's and to the oracle's.  Rows whose list
 // does not fit (kKnnEntCap words, kKnnSlotCap slots, kKnnCap candidates after tightening: hundreds of
 // coincident points, NaN coordinates) go to k_knn_exact_rows as before.
@@ -52,9 +51,8 @@ __device__ __forceinline__ float half_sort_asc(float v, int hl)
 // rows are formed at the end, one row per lane.
 constexpr int kPreRows = 64;
 __global__ __launch_bounds__(256) void k_knn_prebound(const double *__restrict__ sorted, int m, int ms, int k, int row0,
-                                                      int nrows, const NnFrame *__restrict__ gframe,
-                                                      double *__restrict__ t_row, float *__restrict__ thr_row,
-                                                      int *__restrict__ cnt_row)
+                                                      int nrows, double *__restrict__ t_row, float *__restrict__ tf_row,
+                                                      float *__restrict__ sqf_row, int *__restrict__ cnt_row)
 {
     __shared__ double wx[kPreRows + kKnnWindow], wy[kPreRows + kKnnWindow], wz[kPreRows + kKnnWindow];
     __shared__ double tl[kPreRows];
@@ -102,7 +100,12 @@ __global__ __launch_bounds__(256) void k_knn_prebound(const double *__restrict__
         // fewer than k finite lane minima (tiny or mostly non-finite targets, a NaN row): everything is listed
         const bool open = !(T < 1.0e299);
         t_row[local] = open ? __builtin_inf() : T;
-        thr_row[local] = open ? 3.4028235e38f : all_splits_tau(wx[r - lo], wy[r - lo], wz[r - lo], *gframe, T, sqrt(T));
+        // fp32 images for the coarse pass's per-split thresholds (MODE 2, nn_mfma.h), rounded up; +Inf lists everything
+        const float tf = open ? __builtin_inff() : (float)T; // (T came from an fp32 value: exact)
+        float sq = __builtin_amdgcn_sqrtf(tf);
+        sq = sq < 3.0e38f ? __uint_as_float(__float_as_uint(sq) + 2u) : sq; // (1 ulp of v_sqrt_f32 and one more)
+        tf_row[local] = tf;
+        sqf_row[local] = sq;
         cnt_row[local] = 0;
     }
 }

@@ -7,7 +7,7 @@
 //   RowBounds (kernels.h) ub(row) = |row - target[previous match]|^2 exactly (and its fp32 images, rounded up), left by
 //                        the kernel that moves the rows after a pass (k_finish_step_transform, k_step_transform,
 //                        k_transform): the previous matches' coordinates are fetched under that kernel's serial step
-//   k_nn_coarse_bounded  the all-pairs pass with the MODE 3 epilogue: the columns (slots of 64 sorted targets) whose
+//   k_nn_coarse_bounded  the all-pairs pass with the MODE 2 epilogue: the columns (slots of 64 sorted targets) whose
 //                        minimum is <= tau_s(ub(row)), the bound on the coarse value of any target of split s within
 //                        ub (nn_mfma.h), are listed per row, 16 columns to a word -- one word per row, rarely two,
 //                        instead of 6 B per (row, split): 29 MB written and read back per C3 pass before, 2.9 GB at

@@ -429,12 +429,12 @@ __device__ __forceinline__ float tag_low5(float x, unsigned tag)
 
 // MODE 0: 1-NN epilogue -> coarse[split][n] = (tagged min, second min over the 32 columns)
 // MODE 1: k-NN epilogue  -> slotmin[query][split*32 + column], every column minimum kept (bf16, rounded down)
-// MODE 2: k-NN epilogue for rows that come with a bound (knn_lists.h): the columns whose minimum is <= the
-//         row's threshold are LISTED per row, 16 columns to a word; nothing else is written
-// MODE 3: the same lists for the rows of an ICP pass (nn_bounded.h), the threshold formed per (row, SPLIT) from the row's
-//         distance bound and the split's own frame term -- the bound that holds for every split carries 52 u a^2 with
-//         a = the whole target's extent, which on a 100 m cloud is a third of a nearest-neighbour distance squared and
-//         listed a second slot for a third of the rows
+// MODE 2: epilogue for rows that come WITH a bound on the distance they look within (normal estimation, knn_lists.h; the
+//         ICP loop from its second pass on, nn_bounded.h): the columns whose minimum is <= tau_s(bound) are LISTED per
+//         row, 16 columns to a word; nothing else is written.  The threshold is formed per (row, SPLIT) from the row's
+//         bound and the split's own frame term: the bound that holds for every split carries 52 u a^2 with a = the
+//         whole target's extent, which on a 100 m cloud is a third of a nearest-neighbour distance squared and listed a
+//         second slot for a third of the rows.
 // QT = 32-query tiles per wave (even); WAVES = waves per workgroup.  (Tried and dropped, see
 // scripts/micro/README.md: issuing a tile's min3 one tile behind its MFMAs, keeping the next B chunk
 // in flight in registers, QT = 4: none beat this form, all cost occupancy.)
@@ -442,12 +442,11 @@ __device__ __forceinline__ float tag_low5(float x, unsigned tag)
 // The three parts of a wave's work on 32*QT queries against one split, shared by the kernels below.
 
 // MODE 2's output: per row a count and up to `cap` words (split << 17 | half << 16 | mask of the 16 columns
-// split*32 + half*16 + bit whose minimum is under thr[row]); rows are numbered from the launch's first row.
+// split*32 + half*16 + bit whose minimum is under the threshold); rows are numbered from the launch's first row.
 constexpr int kKnnEntCap = 32;
 struct KnnLists {
-    const float *thr; // [rows] MODE 2: bound on the coarse value of anything the row needs to look at; MODE 3: the row's
-                      //        distance bound itself, fp32 rounded up
-    const float *sq;  // [rows] MODE 3: its square root, rounded up
+    const float *thr; // [rows] the row's distance bound, fp32 rounded up
+    const float *sq;  // [rows] its square root, rounded up
     int *cnt;         // [rows] words appended (may exceed `cap`: the row then takes its reader's exhaustive path)
     unsigned *ent;    // [rows][cap]
     int cap;          // words per row: kKnnEntCap (normal estimation), kNnEntCap (the ICP loop's bounded 1-NN pass)
@@ -482,7 +481,7 @@ __device__ __forceinline__ void coarse_build_a(uint4 *rows, const int lane, cons
             const float ty = __uint_as_float(yh << 16) + __uint_as_float(ym << 16);
             const float tz = __uint_as_float(zh << 16) + __uint_as_float(zm << 16);
             pn[gq] = (tx * tx + ty * ty) + tz * tz;
-            p2[gq] = pn[gq]; // |P|^2 whole (MODE 3's frame term)
+            p2[gq] = pn[gq]; // |P|^2 whole (MODE 2's frame term)
         }
         // leading piece of |P|^2 (truncated: exact difference) goes through the matrix core,
         // the epilogue adds the rest
@@ -536,8 +535,7 @@ __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         float thr_q = 0.f;
-        if (MODE == 2) thr_q = kl.thr[q0 + t * 32 + ql < n ? q0 + t * 32 + ql : n - 1];
-        if (MODE == 3) thr_q = __shfl(thr[t >> 1], (t & 1) * 32 + ql, 64); // (formed lane-per-query like pn)
+        if (MODE == 2) thr_q = __shfl(thr[t >> 1], (t & 1) * 32 + ql, 64); // (formed lane-per-query like pn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + ql] = m[t][r];
         __builtin_amdgcn_wave_barrier();
@@ -556,7 +554,7 @@ __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const
         }
         __builtin_amdgcn_wave_barrier();
         const int iq = q0 + t * 32 + ql;
-        if (MODE == 2 || MODE == 3) {
+        if (MODE == 2) {
             // Nearly every (row, split) pair has nothing under the row's bound: one minimum over the lane's 16
             // columns, one compare, one ballot.  (+Inf / NaN of a far-away or NaN row become kBig like in MODE 1;
             // such a row's bound is FLT_MAX, so it lists everything and is handed to the exact kernel.)
@@ -654,7 +652,7 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
 #pragma unroll
     for (int gq = 0; gq < (QT + 1) / 2; ++gq) {
         thr[gq] = 0.f;
-        if (MODE == 3) {
+        if (MODE == 2) {
             // tau_s(d) of nn_mfma.h's header for d = the row's bound, in fp32 with every input rounded up: a >= |p - c_s| + rho_s
             // from the represented point (within 2^-16 of the true one) and the split's radius, 1e-4 over; the last factor
             // covers this evaluation's own roundings and tau_from_a's 5e-6.  A NaN bound (a row with a non-finite coordinate)
@@ -737,7 +735,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse_rows(
     coarse_unit<2, QT, WAVES, true>(lds, blockIdx.x, blockIdx.y, gridDim.y, rows, n, qstride, Bpack, frames, nullptr, nullptr, kl);
 }
 
-// all pairs, the moved source rows of an ICP pass that come with a bound (nn_bounded.h), MODE 3
+// all pairs, the moved source rows of an ICP pass that come with a bound (nn_bounded.h), MODE 2
 template <int QT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse_bounded(
     const double *__restrict__ qry, int n, const uint4 *__restrict__ Bpack,
@@ -745,7 +743,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse_bounded(
 {
     if (st && st->done) return;
     __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
-    coarse_unit<3, QT, WAVES>(lds, blockIdx.x, blockIdx.y, gridDim.y, qry, n, 0, Bpack, frames, nullptr, nullptr, kl);
+    coarse_unit<2, QT, WAVES>(lds, blockIdx.x, blockIdx.y, gridDim.y, qry, n, 0, Bpack, frames, nullptr, nullptr, kl);
 }
 
 // (Measured and not kept, scripts/micro/README.md: a RESIDENT form -- one 16-wave workgroup per CU stages a
