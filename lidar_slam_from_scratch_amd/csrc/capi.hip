@@ -568,13 +568,11 @@ float *coarse_clock_buffer(icpmi_ctx *ctx, int n, int splits)
 }
 
 // ICPMI_NN_BOUNDED=0: every pass of the ICP loop keeps its coarse minima and certifies afterwards (round 2's form)
+// (read at every call, so that one process can run both forms on the same input: scripts/fuzz_bounded.py)
 bool nn_bounded_enabled()
 {
-    static const bool on = [] {
-        const char *e = getenv("ICPMI_NN_BOUNDED");
-        return !(e && e[0] == '0');
-    }();
-    return on;
+    const char *e = getenv("ICPMI_NN_BOUNDED");
+    return !(e && e[0] == '0');
 }
 
 // The per-row arrays of the bounded pass inside ctx->nn_lists (n rows)

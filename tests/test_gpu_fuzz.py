@@ -15,3 +15,12 @@ def test_fuzz_engines_against_brute_force(oracle, monkeypatch):
     import fuzz_engines
     monkeypatch.setattr(sys, "argv", ["fuzz_engines.py", "150", "20260"])
     assert fuzz_engines.main() == 0
+
+
+def test_fuzz_bounded_passes_against_unbounded(oracle, monkeypatch):
+    """scripts/fuzz_bounded.py: the same registration with the ICP loop's bounded passes (nn_bounded.h) and without, in one
+    process, bit for bit: 60 seeded trials here."""
+    import fuzz_bounded
+    monkeypatch.setattr(sys, "argv", ["fuzz_bounded.py", "60", "7300"])
+    monkeypatch.setenv("ICPMI_NN_BOUNDED", "1")   # (the script flips it per call; restored afterwards)
+    assert fuzz_bounded.main() == 0
