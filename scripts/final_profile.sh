@@ -3,7 +3,8 @@
 # PMC passes (one counter group per pass), secondary workloads.  Output under gpurun_out/final/;
 # the summaries are then copied into profiles/<round>/ (see profiles/README.md).
 # usage: scripts/final_profile.sh a   (bench line, kernel stats, counter passes, secondary workloads)
-#        scripts/final_profile.sh b   (frame stream, A/B runs, small-cloud regime, sensitivity)   -- two gpurun calls of <= 20 min
+#        scripts/final_profile.sh b   (frame stream, A/B runs, small-cloud regime, sensitivity)
+#        scripts/final_profile.sh c   (round 3: lists / bounded passes A/B, normals timing, fuzz runs)   -- three gpurun calls of <= 20 min
 cd "$GRAFT_REPO_ROOT"
 O="$GRAFT_REPO_ROOT/gpurun_out/final"
 mkdir -p "$O"
@@ -27,6 +28,19 @@ timeout -k 10 300 python scripts/engine_compare_lidar.py > "$O/engines_lidar_raw
 timeout -k 10 100 python scripts/event_overhead.py > "$O/event_overhead.txt" 2>&1 || exit 1
 python scripts/prof_summary.py "$O" > "$O/summary.txt" 2>&1
 echo done a
+exit 0
+fi
+if [ "$part" = "c" ]; then
+# normal estimation: round 2's slot minima against the lists (kernel times, then whole calls on three kinds of cloud)
+bash scripts/ab_knn_lists.sh > "$O/ab_knn_lists.txt" 2>&1 || exit 1
+timeout -k 10 300 python scripts/normals_timing.py > "$O/normals_timing.json" 2> "$O/normals_timing.err" || exit 1
+# the ICP loop: unbounded against bounded passes at C3 and at one shard of an 8-way job (12.5k rows)
+bash scripts/ab_nn_bounded.sh > "$O/ab_nn_bounded.txt" 2>&1 || exit 1
+bash scripts/ab_nn_bounded.sh 100000 12500 > "$O/ab_nn_bounded_shard.txt" 2>&1 || exit 1
+rm -rf gpurun_out/nnb_0 gpurun_out/nnb_1 gpurun_out/knnl_0 gpurun_out/knnl_1
+timeout -k 10 300 python scripts/fuzz_bounded.py 3000 > "$O/fuzz_bounded.txt" 2>&1 || exit 1
+timeout -k 10 700 python scripts/fuzz_engines.py 4000 31000 > "$O/fuzz_engines.txt" 2>&1 || exit 1
+echo done c
 exit 0
 fi
 # C5 at stream length: 200 synthetic frames as KITTI .bin, file -> pose, with the oracle loop beside it
