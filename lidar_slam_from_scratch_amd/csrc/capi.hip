@@ -2878,6 +2878,34 @@ int icpmi_get_profile(icpmi_ctx *ctx, icpmi_profile *out)
     return ICPMI_OK;
 }
 
+#ifdef ICPMI_DEBUG_LOOP
+// diagnostic build only (scripts/loop_rows.py): the rows of the last registration as the loop left them -- matches,
+// moved coordinates, and the order the rows were taken in (0..n-1 when they were not sorted)
+extern "C" int icpmi_debug_loop_lists(icpmi_ctx *ctx, double *ub_out, int32_t *cnt_out, uint32_t *ent_out, int64_t n)
+{
+    if (!ctx || !ctx->nn_lists.p || kNnListRowBytes * (size_t)n > ctx->nn_lists.cap) return ICPMI_ERR_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return ICPMI_ERR_HIP;
+    const NnListRows lr = nn_list_rows(ctx, (int)n);
+    if (hipMemcpy(ub_out, lr.ub, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return ICPMI_ERR_HIP;
+    if (hipMemcpy(cnt_out, lr.cnt, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return ICPMI_ERR_HIP;
+    if (hipMemcpy(ent_out, lr.ent, (size_t)n * 4 * kNnEntCap, hipMemcpyDeviceToHost) != hipSuccess) return ICPMI_ERR_HIP;
+    return ICPMI_OK;
+}
+extern "C" int icpmi_debug_loop_rows(icpmi_ctx *ctx, int32_t *idx_out, double *cur_out, uint32_t *perm_out, int64_t n)
+{
+    if (!ctx || (size_t)n * sizeof(int) > ctx->idx.cap || (size_t)n * 24 > ctx->cur.cap) return ICPMI_ERR_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return ICPMI_ERR_HIP;
+    if (hipMemcpy(idx_out, ctx->idx.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return ICPMI_ERR_HIP;
+    if (hipMemcpy(cur_out, ctx->cur.p, (size_t)n * 24, hipMemcpyDeviceToHost) != hipSuccess) return ICPMI_ERR_HIP;
+    if (ctx->src_sort.p && ctx->src_sort.cap >= (size_t)n * 16) {
+        if (hipMemcpy(perm_out, (const unsigned *)ctx->src_sort.p + 3 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return ICPMI_ERR_HIP;
+    } else {
+        for (int64_t i = 0; i < n; ++i) perm_out[i] = (uint32_t)i;
+    }
+    return ICPMI_OK;
+}
+#endif
+
 #if defined(ICPMI_COARSE_CLOCKS) || defined(ICPMI_SMALL_CLOCKS)
 // diagnostic build only: the stamps of the last all-pairs 1-NN pass (4 words per workgroup:
 // s_memtime, s_memrealtime at its start and at its end)

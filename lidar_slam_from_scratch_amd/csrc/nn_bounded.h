@@ -73,9 +73,11 @@ __global__ __launch_bounds__(64 * kResolveWW) void k_nn_resolve_bounded(
     const int nsl = __shfl(incl, 48 + ql, 64); // listed slots of query ql (every sub-lane of the query knows it)
     auto word_base = [](unsigned word) -> int { return (int)(word >> 17) * kCols + (int)((word >> 16) & 1u) * 16; };
     const int first_slot = word_base(w0) + ((w0 & 0xFFFFu) ? __ffs((int)(w0 & 0xFFFFu)) - 1 : 0); // (valid in sub-lane 0)
-    // more words or slots than fit -> the exhaustive search below.  (A finite row with a previous match always lists that
-    // match's slot; one without lists everything.)
-    const bool over = look && (cnt > kNnEntCap || nsl > kNnSlotCap);
+    // More words or slots than fit -> the exhaustive search below.  So does a finite row that lists NOTHING: with a previous
+    // match it lists at least that match's slot and without one everything, unless a coordinate is beyond fp32's range
+    // (a singular step can throw the cloud 1e47 away: fp64 still tells the targets apart, the coarse pass sees NaN and
+    // lists nothing -- found by scripts/fuzz_bounded.py, seed 7368).
+    const bool over = look && (cnt <= 0 || cnt > kNnEntCap || nsl > kNnSlotCap);
     const int nsl_eff = over ? 0 : nsl;
 #if defined(ICPMI_NNB_STOP) && ICPMI_NNB_STOP == 1 /* timing experiments only (WRONG results): where the kernel's time goes */
     if (nsl_eff >= 0) { if (valid && sub == 0) idx[i] = first_slot + (int)bd; return; }
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4_bounded(
     auto word_base = [](unsigned word) -> int { return (int)(word >> 17) * kCols + (int)((word >> 16) & 1u) * 16; };
     const unsigned w0 = (unsigned)__shfl((int)w, quarter * 16, 64);
     const int first_slot = word_base(w0) + ((w0 & 0xFFFFu) ? __ffs((int)(w0 & 0xFFFFu)) - 1 : 0);
-    const bool over = look && (cnt > kNnEntCap || nsl > kNnSlotCap);
+    const bool over = look && (cnt <= 0 || cnt > kNnEntCap || nsl > kNnSlotCap); // (cnt == 0: see k_nn_resolve_bounded)
     const int ns = over ? 0 : nsl;
 
     double d = kMax;
