@@ -171,10 +171,11 @@ __global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restr
                 const int j0 = (sq / kCols) * kSplitTargets + (sq % kCols) * kSlotTargets;
 #pragma unroll
                 for (int o = 0; o < kRuns; ++o) {
-                    // (no clamp: a slot's 64 positions lie inside the array's stride `ms`, m rounded up to 64 -- whatever
-                    // the padding holds is dropped below -- so the addresses are a scalar base + the lane)
+                    // (clamped: a row that lists everything -- no finite bound -- lists the padding slots behind the target's
+                    // last point too, whose positions lie outside the sorted copy)
                     jj[q][o] = j0 + 64 * o + lane;
-                    d[q][o] = sqdist(ICPMI_SX(sorted, ms, jj[q][o]), ICPMI_SY(sorted, ms, jj[q][o]), ICPMI_SZ(sorted, ms, jj[q][o]), px, py, pz);
+                    const int jc = jj[q][o] < m ? jj[q][o] : m - 1;
+                    d[q][o] = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), px, py, pz);
                     if (!(se[q] >= 0 && jj[q][o] < m)) d[q][o] = __builtin_nan(""); // never kept
                 }
             }

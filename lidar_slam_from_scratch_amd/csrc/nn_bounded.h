@@ -94,10 +94,11 @@ __global__ __launch_bounds__(64 * kResolveWW) void k_nn_resolve_bounded(
         const int j0 = (slot / kCols) * kSplitTargets + (slot % kCols) * kSlotTargets + l16;
 #pragma unroll
         for (int o = 0; o < kSlotTargets / 16; ++o) {
-            // (no clamp: a slot's 64 positions lie inside the sorted copy's and perm's allocation; padding is dropped by jj < m)
-            const int jj = j0 + 16 * o;
-            const int oj = (int)perm[jj < m ? jj : m - 1];
-            const double dd = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), qx[r], qy[r], qz[r]);
+            // (clamped: with a bound beyond the padding's stand-in distance a row lists padding slots too, whose positions
+            // lie outside the sorted copy; dropped by jj < m)
+            const int jj = j0 + 16 * o, jc = jj < m ? jj : m - 1;
+            const int oj = (int)perm[jc];
+            const double dd = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), qx[r], qy[r], qz[r]);
             if (act && jj < m && (dd < d[r] || (dd == d[r] && oj < jo[r]))) {
                 d[r] = dd;
                 jo[r] = oj;
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4_bounded(
         const int j0 = (slot / kCols) * kSplitTargets + (slot % kCols) * kSlotTargets + ql;
 #pragma unroll
         for (int o = 0; o < kSlotTargets / 16; ++o) {
-            const int jj = j0 + 16 * o; // (no clamp for the coordinates: see k_nn_resolve_bounded)
-            const int oj = (int)perm[jj < m ? jj : m - 1];
-            const double dd = sqdist(ICPMI_SX(sorted, ms, jj), ICPMI_SY(sorted, ms, jj), ICPMI_SZ(sorted, ms, jj), px, py, pz);
+            const int jj = j0 + 16 * o, jc = jj < m ? jj : m - 1; // (clamped: see k_nn_resolve_bounded)
+            const int oj = (int)perm[jc];
+            const double dd = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), px, py, pz);
             if (act && jj < m && (dd < d || (dd == d && oj < jo))) {
                 d = dd;
                 jo = oj;
