@@ -16,34 +16,51 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from fuzz_engines import cloud
 
 
+KINDS = ["uniform", "clusters", "plane", "line", "grid", "mixed"]
+
+
+def make_case(seed):
+    """The registration of trial `seed` (scripts/loop_rows.py rebuilds single cases from it): source, target, iterations,
+    tolerance, a description.  Seeds from 40000 up also draw offsets of 1e5 cloud sizes."""
+    rng = np.random.default_rng(seed)
+    n_t = int(rng.choice([33000, 40000, 70000, 120000]))          # more than 16 splits: the general kernels
+    n_s = int(rng.choice([4096, 5000, 12500, 32768, 32769, 50000]))
+    scale = float(10.0 ** rng.integers(-2, 3))
+    offset = rng.uniform(-1, 1, 3) * float(rng.choice([0.0, 1.0, 1e3] if seed < 40000 else [0.0, 1.0, 1e3, 1e5]))
+    tk = str(rng.choice(KINDS))
+    tgt = cloud(rng, n_t, tk, scale, offset)
+    if rng.random() < 0.5:
+        pick = rng.choice(n_t, min(n_s, n_t), replace=False)
+        src = tgt[pick] + rng.normal(0, 1e-3 * scale, (pick.shape[0], 3))
+        sk = "subset"
+    else:
+        sk = str(rng.choice(KINDS))
+        src = cloud(rng, n_s, sk, scale, offset)
+    motion = float(rng.choice([1e-4, 1e-2, 0.3, 3.0]))
+    T = synth.make_transform(rng.normal(0, 0.05 * min(motion, 1.0), 3), rng.normal(0, motion, 3) * scale)
+    c = tgt.mean(axis=0)
+    src = np.ascontiguousarray((src - c) @ T[:3, :3].T + T[:3, 3] + c)
+    nanrows = False
+    if rng.random() < 0.2:
+        src[rng.integers(0, src.shape[0])] = np.nan
+        src[rng.integers(0, src.shape[0]), 2] = np.inf
+        nanrows = True
+    iters = int(rng.choice([2, 5, 9]))
+    tol = 0.0 if rng.random() < 0.5 else 1e-6
+    return src, tgt, iters, tol, dict(target=tk, source=sk, scale=scale, motion=motion, nanrows=nanrows, n_t=n_t, n_s=src.shape[0])
+
+
 def main():
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     ctx = capi.Context(device=0, search=capi.SEARCH_MFMA_BF16, profile=2)
-    kinds = ["uniform", "clusters", "plane", "line", "grid", "mixed"]
     bad, bounded_total, exhaustive_total = 0, 0, 0
     t0 = time.time()
     for t in range(trials):
         seed = seed0 + t
-        rng = np.random.default_rng(seed)
-        n_t = int(rng.choice([33000, 40000, 70000, 120000]))          # more than 16 splits: the general kernels
-        n_s = int(rng.choice([4096, 5000, 12500, 32768, 32769, 50000]))
-        scale = float(10.0 ** rng.integers(-2, 3)); offset = rng.uniform(-1, 1, 3) * float(rng.choice([0.0, 1.0, 1e3]))
-        tgt = cloud(rng, n_t, str(rng.choice(kinds)), scale, offset)
-        if rng.random() < 0.5:
-            pick = rng.choice(n_t, min(n_s, n_t), replace=False)
-            src = tgt[pick] + rng.normal(0, 1e-3 * scale, (pick.shape[0], 3))
-        else:
-            src = cloud(rng, n_s, str(rng.choice(kinds)), scale, offset)
-        motion = float(rng.choice([1e-4, 1e-2, 0.3, 3.0]))
-        T = synth.make_transform(rng.normal(0, 0.05 * min(motion, 1.0), 3), rng.normal(0, motion, 3) * scale)
-        c = tgt.mean(axis=0)
-        src = np.ascontiguousarray((src - c) @ T[:3, :3].T + T[:3, 3] + c)
-        if rng.random() < 0.2:
-            src[rng.integers(0, src.shape[0])] = np.nan
-            src[rng.integers(0, src.shape[0]), 2] = np.inf
-        iters = int(rng.choice([2, 5, 9]))
-        cfg = capi.Context.make_config(iters, 0.0 if rng.random() < 0.5 else 1e-6, 0.0)
+        src, tgt, iters, tol, info = make_case(seed)
+        n_t = info["n_t"]
+        cfg = capi.Context.make_config(iters, tol, 0.0)
         out = {}
         for knob in ("1", "0"):
             os.environ["ICPMI_NN_BOUNDED"] = knob

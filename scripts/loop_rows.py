@@ -22,7 +22,7 @@ import torch  # noqa: F401
 from lidar_slam_from_scratch_amd import capi
 L = capi.load_library(so)
 L.icpmi_debug_loop_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_int64]
-from dbg_fuzz_case import make
+from fuzz_bounded import make_case as make
 
 seed = int(sys.argv[1])
 src, tgt, iters, tol, info = make(seed)
