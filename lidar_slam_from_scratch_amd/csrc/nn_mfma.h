@@ -50,6 +50,12 @@
 //     2^-19 d (both relative parts, 3.8e-6 together, are inside the 5e-6 inflation of tau).
 //   52 u a^2 is used.
 //
+// Round 3: where a row comes WITH a bound on the distance it looks within, the coarse pass keeps no minima at all -- its
+// epilogue (MODE 2) lists the slots under the bound's per-split threshold and the resolve scans the listed slots:
+// knn_lists.h (normal estimation: the bound from the target's Morton order) and nn_bounded.h (the ICP loop from its second
+// pass on: the bound from each row's previous match).  The forms described above remain for a call's first pass, the
+// stand-alone searches and the pruned engine.
+//
 // Engine 3 (ICPMI_SEARCH_MFMA_PRUNED, opt-in) runs the same coarse unit and the same resolve on
 // fewer (query block, split) units: k_transform_bounds / k_knn_block_bounds bound, per block of
 // 512 queries, the distance within which every query finds its answer, cull_block keeps the
