@@ -616,7 +616,17 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
         {
             StageTimer tc(ctx, ST_COARSE);
             const KnnLists kl{ubf_row, sqf_row, cnt_row, ent_row, kNnEntCap};
-            if (coarse_half_units(ctx, n, splits)) {
+            if (pruned_pass >= 0) {
+                // the pruned engine's surviving units, list epilogue: a row's list then holds slots of evaluated splits only,
+                // and every split that can hold a target within the row's bound IS evaluated (the block's bound is the
+                // largest of its rows')
+                unsigned *cnt = (unsigned *)((char *)ctx->nn_misc.p + 160);
+                hipLaunchKernelGGL((k_nn_coarse_list<2, false, kCoarseQT, kCoarseWaves>), dim3(2 * ctx->cu_count), dim3(kCoarseThreads), 0,
+                                   ctx->stream, d_qry, n, (size_t)0, (const uint4 *)ctx->bpack.p, frames, (float2 *)nullptr,
+                                   (float *)nullptr, splits, (const unsigned *)ctx->work.p, (const unsigned *)(cnt + (pruned_pass & 1)),
+                                   cnt + ((pruned_pass + 1) & 1), (unsigned)(((n + kCoarseQueries - 1) / kCoarseQueries) * splits),
+                                   counters + 2, st, kl);
+            } else if (coarse_half_units(ctx, n, splits)) {
                 constexpr int per = kCoarseQueries / kCoarseQT; // queries per workgroup with one tile per wave
                 hipLaunchKernelGGL((k_nn_coarse_bounded<1, kCoarseWaves>), dim3((n + per - 1) / per, splits), dim3(kCoarseThreads), 0,
                                    ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames, kl, st);
@@ -1157,7 +1167,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
 
     // Bounded passes (nn_bounded.h): every kernel that moves the rows after a pass also leaves, per row, the exact distance
     // to the target it was just matched with -- the bound the next pass searches behind.
-    const bool bounded_loop = sorted_rows_loop && nn_bounded_enabled();
+    const bool bounded_loop = (sorted_rows_loop || (pruned && resolve_waves(n) != -32)) && nn_bounded_enabled();
     RowBounds rb{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     if (bounded_loop) {
         if ((rc = reserve(ctx, ctx->nn_lists, kNnListRowBytes * (size_t)n + 64))) return rc;
@@ -1256,7 +1266,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                 hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, (const double *)cur,
                                    (const unsigned *)nullptr, cur, n, (const IcpState *)st, 0, 1, d_tgt,
                                    (const int *)idx, m, frames, splits, blk_cnt, blk_list, work,
-                                   work_cnt + (pass_no & 1) /* the next pass's counter */);
+                                   work_cnt + (pass_no & 1) /* the next pass's counter */, rb);
             else
                 hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
                                    cur, cur, n, st, 0, 1, (const unsigned *)nullptr, rb);

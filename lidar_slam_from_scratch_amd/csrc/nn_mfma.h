@@ -768,7 +768,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
     const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/,
     float *__restrict__ slotmin /*[n][nsplits*32], MODE 1*/, int nsplits,
     const unsigned *__restrict__ work, const unsigned *__restrict__ count, unsigned *__restrict__ count_next,
-    unsigned total_units, unsigned long long *__restrict__ culled_count, const IcpState *__restrict__ st)
+    unsigned total_units, unsigned long long *__restrict__ culled_count, const IcpState *__restrict__ st,
+    const KnnLists kl = KnnLists{nullptr, nullptr, nullptr, nullptr, 0} /* MODE 2: the rows' lists (nn_bounded.h) */)
 {
     if (st && st->done) return;
     __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
     for (unsigned w = blockIdx.x; w < cnt; w += gridDim.x) {
         const unsigned unit = (unsigned)__builtin_amdgcn_readfirstlane((int)work[w]); // uniform: keep it scalar
         const int bx = (int)(unit / (unsigned)nsplits), s = (int)(unit % (unsigned)nsplits);
-        coarse_unit<MODE, QT, WAVES, QSOA>(lds, bx, s, nsplits, qry, n, qstride, Bpack, frames, coarse, slotmin);
+        coarse_unit<MODE, QT, WAVES, QSOA>(lds, bx, s, nsplits, qry, n, qstride, Bpack, frames, coarse, slotmin, kl);
         __syncthreads(); // the epilogue's LDS is the next unit's operand buffer
     }
 }
@@ -839,7 +840,8 @@ __global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
     const IcpState *__restrict__ st, int which, int honour_done, const double *__restrict__ tgt,
     const int *__restrict__ prev_idx, int m, const SplitFrame *__restrict__ frames, int nsplits,
     int *__restrict__ blk_cnt, int *__restrict__ blk_list /*[blocks][nsplits]*/,
-    unsigned *__restrict__ work, unsigned *__restrict__ work_count)
+    unsigned *__restrict__ work, unsigned *__restrict__ work_count,
+    const RowBounds rb = RowBounds{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr} /* ub != nullptr: the rows' bounds for a bounded pass */)
 {
     static_assert(kCoarseQueries == 512, "one block of this kernel == one query block of k_nn_coarse");
     if (honour_done && st->done) return;
@@ -861,6 +863,20 @@ __global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
         if (prev_idx) {
             const int j = prev_idx[i];
             if ((unsigned)j < (unsigned)m) ub = sqdist(tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2], p[0], p[1], p[2]);
+        }
+        if (rb.ub) { // the same distance, per row, for the bounded pass that follows (RowBatch::finish's images)
+            float ubf = __builtin_nanf(""), sqf = 0.f;
+            const bool fin = __builtin_isfinite(p[0]) && __builtin_isfinite(p[1]) && __builtin_isfinite(p[2]);
+            if (fin) {
+                ubf = (float)ub;
+                ubf = (double)ubf < ub ? __uint_as_float(__float_as_uint(ubf) + 1u) : ubf;
+                sqf = __builtin_amdgcn_sqrtf(ubf);
+                sqf = sqf < 3.0e38f ? __uint_as_float(__float_as_uint(sqf) + 2u) : sqf;
+            }
+            rb.ub[i] = fin ? ub : __builtin_inf();
+            rb.ubf[i] = ubf;
+            rb.sqf[i] = sqf;
+            rb.cnt[i] = 0;
         }
     }
     __shared__ double red[8][7];
