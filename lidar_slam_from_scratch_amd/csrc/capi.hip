@@ -782,7 +782,9 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
             return (long)ICPMI_KNN_CHUNK_DEFAULT_MB << 20;
         }();
         // all-pairs engine, rows in the target's Morton order: bound first, lists instead of minima (knn_lists.h)
-        const bool lists = by_sorted_row && !ctx->nn_pruned;
+        // (pruned engine: the same lists on the units that survive the box test against the block's largest row bound)
+        const bool lists = by_sorted_row && (knn_lists_enabled() || !ctx->nn_pruned);
+        const bool lists_culled = lists && ctx->nn_pruned;
         constexpr long kListRowBytes = sizeof(double) + 2 * sizeof(float) + sizeof(int) + sizeof(unsigned) * kKnnEntCap;
         const long budget = lists ? (1l << 30) : by_sorted_row ? (4l << 30) : knn_budget;
         long chunk = (budget / (lists ? kListRowBytes : (long)nslots * 2)) / kCoarseQueries * kCoarseQueries; // 2 bytes per slot minimum (bf16)
@@ -796,7 +798,7 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
         const int cblocks = (int)(chunk / kCoarseQueries);
         int *blk_cnt = nullptr, *blk_list = nullptr;
         unsigned *work = nullptr, *work_cnt = nullptr;
-        if (by_sorted_row && !lists) {
+        if (by_sorted_row && (!lists || lists_culled)) {
             if ((rc = reserve(ctx, ctx->blk_lists, sizeof(int) * (size_t)cblocks * ((size_t)splits + 1)))) return rc;
             if ((rc = reserve(ctx, ctx->work, sizeof(unsigned) * (size_t)cblocks * (size_t)splits))) return rc;
             blk_cnt = (int *)ctx->blk_lists.p;
@@ -815,7 +817,15 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                 const KnnLists kl{tf_row, sqf_row, cnt_row, ent_row, kKnnEntCap};
                 hipLaunchKernelGGL(k_knn_prebound, dim3((nq + kPreRows - 1) / kPreRows), dim3(256), 0, s, sorted, m, ctx->nn_ms, k, (int)c0, nq,
                                    t_row, tf_row, sqf_row, cnt_row);
-                if (coarse_half_units(ctx, nq, splits)) {
+                if (lists_culled) {
+                    HIP_TRY(ctx, hipMemsetAsync(work_cnt, 0, sizeof(unsigned), s));
+                    hipLaunchKernelGGL(k_knn_block_bounds, dim3(nblk), dim3(kCoarseQueries), 0, s, sorted, m, ctx->nn_ms, (int)c0, nq,
+                                       std::min(k, 64), frames, splits, blk_cnt, blk_list, work, work_cnt, (const double *)t_row);
+                    hipLaunchKernelGGL((k_nn_coarse_list<2, true, kCoarseQT, kCoarseWaves>), dim3(2 * ctx->cu_count), dim3(kCoarseThreads),
+                                       0, s, sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, (float2 *)nullptr,
+                                       (float *)nullptr, splits, (const unsigned *)work, (const unsigned *)work_cnt,
+                                       (unsigned *)nullptr, 0u, (unsigned long long *)nullptr, (const IcpState *)nullptr, kl);
+                } else if (coarse_half_units(ctx, nq, splits)) {
                     constexpr int per = kCoarseQueries / kCoarseQT;
                     hipLaunchKernelGGL((k_nn_coarse_rows<1, kCoarseWaves>), dim3((nq + per - 1) / per, splits), dim3(kCoarseThreads), 0,
                                        s, sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, kl);

@@ -957,7 +957,8 @@ __global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
 __global__ __launch_bounds__(kCoarseQueries) void k_knn_block_bounds(
     const double *__restrict__ sorted, int m, int ms, int row0, int nrows, int kk,
     const SplitFrame *__restrict__ frames, int nsplits, int *__restrict__ blk_cnt,
-    int *__restrict__ blk_list, unsigned *__restrict__ work, unsigned *__restrict__ work_count)
+    int *__restrict__ blk_list, unsigned *__restrict__ work, unsigned *__restrict__ work_count,
+    const double *__restrict__ t_row = nullptr /* the rows' own bounds (k_knn_prebound), indexed from the launch's first row: the block's bound is their largest */)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int local = blockIdx.x * kCoarseQueries + threadIdx.x;
@@ -990,6 +991,16 @@ __global__ __launch_bounds__(kCoarseQueries) void k_knn_block_bounds(
         ub *= 1.0 + 1e-12;
         // fewer rows here than the slot holds in the cloud (chunk edge), or fewer than k: no bound
         if (here < in_cloud || in_cloud < kk || !(ub == ub)) ub = __builtin_inf();
+    }
+    if (t_row) { // every row's k-th neighbour lies within its own bound: the largest over the wave's rows serves them all
+        double t = valid ? t_row[local] : 0.0;
+        t = t == t ? t : __builtin_inf();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(t, off, 64);
+            t = o > t ? o : t;
+        }
+        ub = here > 0 ? t * (1.0 + 1e-12) : 0.0;
     }
     __shared__ double red[8][7];
     __shared__ double sbox[7];
