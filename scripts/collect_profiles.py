@@ -17,7 +17,7 @@ for f in ("bench.json", "bench_20.json", "bench_extra.json", "engines_100k.json"
           "event_overhead.txt", "sequence_200.json", "sequence_200_noprefetch.json", "sequence_200_map.json", "summary.txt", "ab_r1_r2.json", "threshold_sweep.json",
           "ab_fuse_finish.json", "coarse_clock.json", "ab_small.json", "small_clock.json", "batch_timing.json", "iteration_sensitivity.json",
           "stream_threads.txt", "ab_knn_lists.txt", "normals_timing.json", "ab_nn_bounded.txt", "ab_nn_bounded_shard.txt",
-          "fuzz_bounded.txt", "fuzz_engines.txt"):
+          ):   # (the fuzz logs are trimmed to their last lines by hand)
     if os.path.exists(os.path.join(F, f)) and os.path.getsize(os.path.join(F, f)) > 0:
         shutil.copy(os.path.join(F, f), os.path.join(P, f))
 shutil.copy(newest(F + "/stats/**/*kernel_stats.csv"), P + "/kernel_stats.csv")
