@@ -32,7 +32,10 @@ namespace icpmi {
 constexpr int kNnSlotCap = 16; // listed slots scanned per row
 
 // Q = 16 queries per wave, the lane layout, workgroup shape and sums of k_nn_resolve<16>.
-__global__ __launch_bounds__(64 * kResolveWW) void k_nn_resolve_bounded(
+#ifndef ICPMI_BOUNDED_OCC
+#define ICPMI_BOUNDED_OCC 7 /* waves per SIMD the register allocation must allow: at 7 (72 VGPRs, 3 dwords spilled) all 6,252 waves of a C3 pass are resident at once -- 5 / 6 / 7 / 8: 28.4 / 28.5 / 25.6 / 28.8 us (scripts/sweep_bounded_occ.sh) */
+#endif
+__global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu(ICPMI_BOUNDED_OCC, 8))) void k_nn_resolve_bounded(
     const double *__restrict__ qry, int n, const double *__restrict__ sorted, const unsigned *__restrict__ perm, int m, int ms,
     int splits, const SplitFrame *__restrict__ frames, const double *__restrict__ ub_row, const int *__restrict__ cnt_row,
     const unsigned *__restrict__ ent_row, int *__restrict__ idx /* in: previous match, out: this pass's */,
