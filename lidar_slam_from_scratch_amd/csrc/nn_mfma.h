@@ -1827,6 +1827,9 @@ __device__ __forceinline__ void knn_rank_write(const double *cd, int *cj, int *c
                                                const int k, const int lane, int *__restrict__ out,
                                                const unsigned *__restrict__ perm = nullptr)
 {
+    // fewer candidates than k (a row with a NaN coordinate keeps none: no distance compares): the places left over say "no
+    // neighbour", as k_knn_exact_rows writes them -- never what an earlier call left in the buffer
+    for (int r = total + lane; r < k; r += 64) out[r] = 0x7fffffff;
     bool clash = false;
     for (int e = lane; e < total; e += 64) {
         const double d = cd[e];
