@@ -986,6 +986,58 @@ print(json.dumps(out))
     assert all(v["iters"] >= 1 for v in legs["1"].values())
 
 
+def test_normal_lists_give_the_slot_minimum_form_bits():
+    """knn_lists.h: normal estimation with the bound first and lists instead of slot minima, against round 2's form
+    (ICPMI_KNN_LISTS=0), same GPU, child processes: both claim the exact k smallest by (distance, original index), so
+    the normals must agree BIT FOR BIT also where the oracle's kd-tree would break ties its own way -- an integer grid
+    with eight-fold duplicates (every neighbourhood full of exact ties, far more equidistant candidates than the
+    128 a row keeps: tighten, go round again, or hand the row to the exact kernel), clusters, a line, a plane, mixed
+    scales, a LiDAR-like frame, rows with NaN / infinite coordinates, one split and many; both MFMA engines."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r'''
+import sys, json, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/scripts")
+import numpy as np
+from lidar_slam_from_scratch_amd import capi, synth
+from fuzz_engines import cloud
+rng = np.random.default_rng(3)
+clouds = {}
+g = rng.integers(-5, 6, (1500, 3)).astype(np.float64)
+clouds["grid_dups_12k"] = np.repeat(g, 8, axis=0)[rng.permutation(12000)]
+clouds["grid_70k"] = rng.integers(-20, 21, (70000, 3)).astype(np.float64) * 0.25
+for kind in ("clusters", "line", "plane", "mixed"):
+    clouds[kind + "_9k"] = cloud(rng, 9000, kind, 1.0, np.zeros(3))
+    clouds[kind + "_40k"] = cloud(rng, 40000, kind, 10.0, np.array([1e3, -2e3, 50.0]))
+clouds["lidar"] = synth.lidar_frame(0)
+clouds["tiny_300"] = cloud(rng, 300, "uniform", 1.0, np.zeros(3))
+bad = cloud(rng, 9000, "uniform", 1.0, np.zeros(3)); bad[5] = np.nan; bad[77, 1] = np.inf
+clouds["nan_rows_9k"] = bad
+bad = cloud(rng, 50000, "uniform", 1.0, np.zeros(3)); bad[5] = np.nan; bad[4077, 1] = -np.inf
+clouds["nan_rows_50k"] = bad
+out = {}
+for engine in (capi.SEARCH_MFMA_BF16, capi.SEARCH_MFMA_PRUNED):
+    ctx = capi.Context(device=0, search=engine)
+    for name, pts in clouds.items():
+        for k in (20, 5):
+            nrm = ctx.estimate_normals(pts, k)
+            out["%%d %%s k%%d" %% (engine, name, k)] = hashlib.sha256(np.ascontiguousarray(nrm).tobytes()).hexdigest()
+    ctx.close()
+print(json.dumps(out))
+''' % (root, root)
+    legs = {}
+    for knob in ("0", "1"):
+        env = dict(os.environ, ICPMI_KNN_LISTS=knob)
+        r = subprocess.run([sys.executable, "-c", child], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        legs[knob] = json.loads(r.stdout.strip().splitlines()[-1])
+    differing = [k for k in legs["0"] if legs["0"][k] != legs["1"][k]]
+    assert not differing, differing
+
+
 def test_bounded_pass_gives_the_unbounded_pass_bits():
     """nn_bounded.h: from its second pass on the ICP loop searches behind the rows' previous matches -- the coarse
     pass lists the slots under each row's bound instead of keeping its minima, the resolve scans the listed slots
