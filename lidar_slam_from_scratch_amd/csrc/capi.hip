@@ -785,11 +785,14 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
         // (pruned engine: the same lists on the units that survive the box test against the block's largest row bound)
         const bool lists = by_sorted_row && (knn_lists_enabled() || !ctx->nn_pruned);
         const bool lists_culled = lists && ctx->nn_pruned;
+        // rows that are not a range of sorted positions (arbitrary queries: icpmi_k_nearest; rows by point index:
+        // icpmi_estimate_normals_rows) get their place in the sorted order from their Morton key (k_knn_prebound_q)
+        const bool lists_q = !by_sorted_row && knn_lists_enabled();
         constexpr long kListRowBytes = sizeof(double) + 2 * sizeof(float) + sizeof(int) + sizeof(unsigned) * kKnnEntCap;
-        const long budget = lists ? (1l << 30) : by_sorted_row ? (4l << 30) : knn_budget;
-        long chunk = (budget / (lists ? kListRowBytes : (long)nslots * 2)) / kCoarseQueries * kCoarseQueries; // 2 bytes per slot minimum (bf16)
+        const long budget = (lists || lists_q) ? (1l << 30) : by_sorted_row ? (4l << 30) : knn_budget;
+        long chunk = (budget / ((lists || lists_q) ? kListRowBytes : (long)nslots * 2)) / kCoarseQueries * kCoarseQueries; // 2 bytes per slot minimum (bf16)
         chunk = std::max<long>(kCoarseQueries, std::min<long>(chunk, ((long)rows + kCoarseQueries - 1) / kCoarseQueries * kCoarseQueries));
-        if ((rc = reserve(ctx, ctx->slotmin, lists ? (size_t)kListRowBytes * chunk : sizeof(unsigned short) * (size_t)chunk * nslots))) return rc;
+        if ((rc = reserve(ctx, ctx->slotmin, (lists || lists_q) ? (size_t)kListRowBytes * chunk : sizeof(unsigned short) * (size_t)chunk * nslots))) return rc;
         if ((rc = reserve(ctx, ctx->fb_list, sizeof(int) * ((size_t)rows + 16)))) return rc;
         int *fb_count = (int *)ctx->fb_list.p, *fb_list = fb_count + 16;
         HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, sizeof(int), s));
@@ -832,8 +835,28 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                 } else
                     hipLaunchKernelGGL((k_nn_coarse_rows<kCoarseQT, kCoarseWaves>), dim3(nblk, splits), dim3(kCoarseThreads), 0, s,
                                        sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, kl);
-                hipLaunchKernelGGL(k_knn_resolve_lists, dim3((nq + 3) / 4), dim3(256), 0, s, sorted, perm, m, ctx->nn_ms, k, (int)c0,
-                                   nq, (const double *)t_row, (const int *)cnt_row, (const unsigned *)ent_row, knn, fb_list, fb_count);
+                hipLaunchKernelGGL(k_knn_resolve_lists<false>, dim3((nq + 3) / 4), dim3(256), 0, s, (const double *)nullptr, sorted, perm, m,
+                                   ctx->nn_ms, k, (int)c0, nq, (const double *)t_row, (const int *)cnt_row, (const unsigned *)ent_row, knn,
+                                   fb_list, fb_count);
+            } else if (lists_q) {
+                double *t_row = (double *)ctx->slotmin.p;
+                float *tf_row = (float *)(t_row + chunk), *sqf_row = tf_row + chunk;
+                int *cnt_row = (int *)(sqf_row + chunk);
+                unsigned *ent_row = (unsigned *)(cnt_row + chunk);
+                const KnnLists kl{tf_row, sqf_row, cnt_row, ent_row, kKnnEntCap};
+                hipLaunchKernelGGL(k_knn_prebound_q, dim3((nq + 7) / 8), dim3(256), 0, s, d_qry, (int)c0, nq, sorted,
+                                   (const unsigned *)ctx->sort_keys.p + (size_t)m /* the sorted keys */, m, ctx->nn_ms, k,
+                                   (const NnFrame *)ctx->nn_misc.p, t_row, tf_row, sqf_row, cnt_row);
+                if (coarse_half_units(ctx, nq, splits)) {
+                    constexpr int per = kCoarseQueries / kCoarseQT;
+                    hipLaunchKernelGGL((k_nn_coarse_bounded<1, kCoarseWaves>), dim3((nq + per - 1) / per, splits), dim3(kCoarseThreads), 0,
+                                       s, d_qry + 3 * c0, nq, (const uint4 *)ctx->bpack.p, frames, kl, (const IcpState *)nullptr);
+                } else
+                    hipLaunchKernelGGL((k_nn_coarse_bounded<kCoarseQT, kCoarseWaves>), dim3(nblk, splits), dim3(kCoarseThreads), 0, s,
+                                       d_qry + 3 * c0, nq, (const uint4 *)ctx->bpack.p, frames, kl, (const IcpState *)nullptr);
+                hipLaunchKernelGGL(k_knn_resolve_lists<true>, dim3((nq + 3) / 4), dim3(256), 0, s, d_qry, sorted, perm, m, ctx->nn_ms, k,
+                                   (int)c0, nq, (const double *)t_row, (const int *)cnt_row, (const unsigned *)ent_row, knn, fb_list,
+                                   fb_count);
             } else if (by_sorted_row) {
                 HIP_TRY(ctx, hipMemsetAsync(work_cnt, 0, sizeof(unsigned), s));
                 hipLaunchKernelGGL(k_knn_block_bounds, dim3(nblk), dim3(kCoarseQueries), 0, s, sorted, m, ctx->nn_ms, (int)c0, nq,
@@ -860,7 +883,7 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                                    fb_list, fb_count, (const int *)nullptr, (const int *)nullptr);
             }
         }
-        hipLaunchKernelGGL(k_knn_exact_rows, dim3(lists ? ctx->cu_count : 1024), dim3(256), (size_t)k * 256 * (sizeof(double) + sizeof(int)),
+        hipLaunchKernelGGL(k_knn_exact_rows, dim3((lists || lists_q) ? ctx->cu_count : 1024), dim3(256), (size_t)k * 256 * (sizeof(double) + sizeof(int)),
                            s, d_pts, m, k, (const int *)fb_list, (const int *)fb_count, knn,
                            by_sorted_row ? perm : (const unsigned *)nullptr, qsep);
         if (ctx->opt.profile) { // visibility only: how many rows took the exact path

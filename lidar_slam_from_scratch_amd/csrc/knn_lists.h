@@ -114,7 +114,74 @@ __global__ __launch_bounds__(256) void k_knn_prebound(const double *__restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restrict__ sorted,
+// The bound for ARBITRARY query points (icpmi_k_nearest): a query has no place in the sorted target, so it is given one --
+// its Morton key in the target's frame, looked up in the sorted keys -- and bounded by the 256 sorted positions around it
+// like a row of the target.  One query per half-wave (k <= 32), the window read from memory (neighbouring queries need
+// not be neighbours in space).
+__global__ __launch_bounds__(256) void k_knn_prebound_q(const double *__restrict__ qry, int q0, int nq,
+                                                        const double *__restrict__ sorted, const unsigned *__restrict__ keys_sorted,
+                                                        int m, int ms, int k, const NnFrame *__restrict__ frame,
+                                                        double *__restrict__ t_row, float *__restrict__ tf_row,
+                                                        float *__restrict__ sqf_row, int *__restrict__ cnt_row)
+{
+    const int lane = threadIdx.x & 63, hl = lane & 31;
+    const int local = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool active = local < nq;
+    const size_t i = (size_t)q0 + (active ? local : nq - 1);
+    const double px = qry[3 * i], py = qry[3 * i + 1], pz = qry[3 * i + 2];
+    // the query's Morton key (k_morton_keys' arithmetic) and its place among the sorted keys (first key >= it)
+    unsigned key;
+    {
+        double ext = 0.0;
+        for (int a = 0; a < 3; ++a) ext = frame->hi[a] - frame->lo[a] > ext ? frame->hi[a] - frame->lo[a] : ext;
+        unsigned q[3];
+        for (int a = 0; a < 3; ++a) {
+            double f = ext > 0.0 ? ((a == 0 ? px : a == 1 ? py : pz) - frame->lo[a]) / ext : 0.0;
+            f = !(f >= 0.0) ? 0.0 : (f > 1.0 ? 1.0 : f);
+            const int qi = (int)(f * 1023.0);
+            q[a] = (unsigned)(qi < 0 ? 0 : (qi > 1023 ? 1023 : qi));
+        }
+        key = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    }
+    int lo_p = 0, hi_p = m;
+    while (lo_p < hi_p) { // (the same trips in every lane of the half: broadcast loads)
+        const int mid = (lo_p + hi_p) >> 1;
+        if (keys_sorted[mid] < key) lo_p = mid + 1;
+        else hi_p = mid;
+    }
+    int w0 = lo_p - kKnnWindow / 2;
+    w0 = w0 + kKnnWindow > m ? m - kKnnWindow : w0;
+    w0 = w0 < 0 ? 0 : w0;
+    const double kInf = 1.7976931348623157e308;
+    double lbest = kInf;
+#pragma unroll
+    for (int c = 0; c < kKnnWindow / 32; ++c) {
+        const int j = w0 + 32 * c + hl;
+        const int jc = j < m ? j : m - 1;
+        const double d = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), px, py, pz);
+        lbest = (j < m && d < lbest) ? d : lbest; // (a NaN distance never enters)
+    }
+    float lbf = (float)lbest;
+    lbf = (double)lbf < lbest ? __uint_as_float(__float_as_uint(lbf) + 1u) : lbf;
+    const int kk = k < 32 ? k : 32;
+    const float tk = __shfl(half_sort_asc(lbf, hl), (lane & 32) + kk - 1, 64);
+    if (hl == 0 && active) {
+        const double T = (double)tk;
+        const bool open = !(T < 1.0e299); // fewer than k finite lane minima, a NaN query: everything is listed
+        t_row[local] = open ? __builtin_inf() : T;
+        const float tf = open ? __builtin_inff() : tk;
+        float sq = __builtin_amdgcn_sqrtf(tf);
+        sq = sq < 3.0e38f ? __uint_as_float(__float_as_uint(sq) + 2u) : sq;
+        tf_row[local] = tf;
+        sqf_row[local] = sq;
+        cnt_row[local] = 0;
+    }
+}
+
+// QROWS: the rows are arbitrary query points (`qry`, N x 3; icpmi_k_nearest) instead of sorted positions of the target
+// itself; list i then belongs to query i.
+template <bool QROWS>
+__global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restrict__ qry, const double *__restrict__ sorted,
                                                            const unsigned *__restrict__ perm, int m, int ms, int k,
                                                            int row0, int nrows, const double *__restrict__ t_row,
                                                            const int *__restrict__ cnt_row,
@@ -132,7 +199,8 @@ __global__ __launch_bounds__(256) void k_knn_resolve_lists(const double *__restr
     const int cnt = cnt_row[local];
     double T = t_row[local];
     const unsigned e = lane < cnt && lane < kKnnEntCap ? ent_row[(size_t)local * kKnnEntCap + lane] : 0u;
-    const double px = ICPMI_SX(sorted, ms, i), py = ICPMI_SY(sorted, ms, i), pz = ICPMI_SZ(sorted, ms, i);
+    const double px = QROWS ? qry[3 * (size_t)i] : ICPMI_SX(sorted, ms, i), py = QROWS ? qry[3 * (size_t)i + 1] : ICPMI_SY(sorted, ms, i),
+                 pz = QROWS ? qry[3 * (size_t)i + 2] : ICPMI_SZ(sorted, ms, i);
     // The listed slots are walked word by word, bit by bit, with SCALAR instructions (a word is read out of its lane;
     // which slot comes next is the same for the whole wave).  Any order: the ranking below is exact.
     int nf = 0;

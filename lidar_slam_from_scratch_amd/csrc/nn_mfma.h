@@ -1829,7 +1829,7 @@ __device__ __forceinline__ void knn_rank_write(const double *cd, int *cj, int *c
 {
     // fewer candidates than k (a row with a NaN coordinate keeps none: no distance compares): the places left over say "no
     // neighbour", as k_knn_exact_rows writes them -- never what an earlier call left in the buffer
-    for (int r = total + lane; r < k; r += 64) out[r] = 0x7fffffff;
+    for (int r = total + lane; r < k; r += 64) out[r] = -1;
     bool clash = false;
     for (int e = lane; e < total; e += 64) {
         const double d = cd[e];
@@ -2293,7 +2293,7 @@ __global__ __launch_bounds__(256) void k_knn_exact_rows(const double *__restrict
                     t = red_t[w];
                 }
             if (tid == t) ++head;
-            if (tid == 0) knn_idx[(size_t)i * k + out] = j;
+            if (tid == 0) knn_idx[(size_t)i * k + out] = j == 0x7fffffff ? -1 : j; // (no candidate left: "no neighbour", icp_mi355x.h)
             __syncthreads();
         }
     }
