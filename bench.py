@@ -36,11 +36,51 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (the pipe k_nn
 FLOP_PER_PAIR = 8.0        # 3 sub + 1 mul + 2 fma
 
 
+_CPU_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+cpu, points, steps = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+os.sched_setaffinity(0, {cpu})                       # before the oracle is loaded or called: one core, no migration
+import numpy as np
+from lidar_slam_from_scratch_amd import synth
+from oracle import oracle as orc
+src, tgt, _ = synth.c3_uniform(points)
+t0 = time.perf_counter()
+r = orc.icp_point_to_plane(src, tgt, max_iterations=steps, tolerance=0.0, min_error=0.0, faithful=True, nthreads=1)
+wall = time.perf_counter() - t0
+print(json.dumps({"wall_s": wall, "loops": int(r.loop_iterations), "loop_s": r.loop_seconds, "setup_s": r.setup_seconds,
+                  "final_s": r.final_seconds, "affinity": sorted(os.sched_getaffinity(0))}))
+"""
+
+
+def cpu_baseline_pinned(points, steps, samples=3):
+    """the 1-thread leg PINNED to one core (os.sched_setaffinity in a child process, before the oracle is
+    called), `samples` separate runs, the median reported with every sample beside it."""
+    import subprocess
+    allowed = sorted(os.sched_getaffinity(0))
+    cpu = allowed[len(allowed) // 2]   # (not core 0, where the kernel's housekeeping tends to land)
+    runs = []
+    for _ in range(samples):
+        r = subprocess.run([sys.executable, "-c", _CPU_CHILD, ROOT, str(cpu), str(points), str(steps)], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError("pinned CPU baseline child failed: " + r.stderr[-400:])
+        runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    rates = [max(x["loops"], 1) / x["wall_s"] for x in runs]
+    med = runs[int(np.argsort(rates)[len(rates) // 2])]
+    return {"value": float(np.median(rates)), "samples_it_per_s": rates, "pinned_cpu": cpu, "affinity_seen_by_child": med["affinity"],
+            "loops": med["loops"], "steady_state_it_per_s": max(med["loops"], 1) / med["loop_s"],
+            "setup_s": med["setup_s"], "loop_s": med["loop_s"], "final_s": med["final_s"]}
+
+
 def cpu_baseline(src, tgt, steps):
     """The oracle (CPU restatement of the reference: kd-tree, two NN passes per iteration,
     single thread like the reference) on the same workload.  Timed as the checker's
-    baseline only -- never part of the measured GPU path."""
+    baseline only -- never part of the measured GPU path.  The 1-thread figure is the median of three
+    runs pinned to one core (cpu_baseline_pinned); the run below, in this process, supplies the result
+    the GPU's pose is compared with."""
     from oracle import oracle as orc
+    pinned = cpu_baseline_pinned(src.shape[0], steps)
     t0 = time.time()
     r = orc.icp_point_to_plane(src, tgt, max_iterations=steps, tolerance=0.0, min_error=0.0,
                                faithful=True, nthreads=1)
@@ -56,11 +96,14 @@ def cpu_baseline(src, tgt, steps):
     return {
         "all_cores_not_the_reference": {"value": max(ra.loop_iterations, 1) / wall_all, "cores": nth,
                                         "note": "oracle, deduplicated NN pass, std threads over queries"},
-        "value": loops / wall, "unit": "ICP iterations/s", "cores": 1, "kind": "port",
-        "sample": "same C3 100k->100k pair, one full call of %d iterations (kd-tree build + "
-                  "20-NN normals + loop + final pass), 1 thread" % loops,
-        "steady_state_it_per_s": loops / r.loop_seconds,
-        "setup_s": r.setup_seconds, "loop_s": r.loop_seconds, "final_s": r.final_seconds,
+        "value": pinned["value"], "unit": "ICP iterations/s", "cores": 1, "kind": "port",
+        "pinned_cpu": pinned["pinned_cpu"], "samples_it_per_s": pinned["samples_it_per_s"],
+        "sample": "same C3 %d->%d pair, one full call of %d iterations (kd-tree build + 20-NN normals + loop + final "
+                  "pass), 1 thread pinned to cpu %d (sched_setaffinity in a child process), median of %d runs"
+                  % (src.shape[0], tgt.shape[0], loops, pinned["pinned_cpu"], len(pinned["samples_it_per_s"])),
+        "unpinned_in_process_it_per_s": loops / wall,
+        "steady_state_it_per_s": pinned["steady_state_it_per_s"],
+        "setup_s": pinned["setup_s"], "loop_s": pinned["loop_s"], "final_s": pinned["final_s"],
         "result": r,
     }
 
@@ -137,11 +180,12 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000)
-    ap.add_argument("--search", type=int, default=0,
-                    help="0 auto (= 2 at this size), 1 exact fp64, 2 bf16 MFMA over all pairs + certified resolve, "
-                         "3 the same with box culling of (query block, target split) units")
-    ap.add_argument("--no-pruned-extra", action="store_true",
-                    help="skip the extra, untimed-by-the-contract run of the opt-in pruned engine")
+    ap.add_argument("--search", type=int, default=2,
+                    help="the engine `value` is measured with: 2 (default) bf16 MFMA over ALL pairs + exact fp64 resolve -- the "
+                         "north_star's brute force, comparable across rounds; 1 exact fp64; 3 the culled engine; 0 whatever "
+                         "AUTO picks.  The library's default engine (AUTO) is always measured beside it: `default_engine`")
+    ap.add_argument("--no-default-engine", action="store_true",
+                    help="skip the second timed series on the library's default engine (AUTO: the culled search at this size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 counter passes behind roofline.traffic")
     ap.add_argument("--repeats", type=int, default=7,
@@ -199,35 +243,44 @@ def main():
     d_src = torch.from_numpy(np.ascontiguousarray(src[lo:hi])).to(dev)
     d_tgt = torch.from_numpy(tgt).to(dev)
     torch.cuda.synchronize()
+    value_search = args.search
 
-    # profile level 1: HIP events around the dominant kernel and the call/loop only
-    # (the fp64 engine has no single dominant kernel bracket: time its whole NN pass instead)
-    ctx = capi.Context(device=local_rank, search=args.search, profile=2 if args.search == 1 else 1)
-    exchange = None
-    if dist is not None:
+    state = {"ctx": None, "exchange": None}
+
+    def open_ctx(search, profile):
+        """A context on `search`; in a multi-rank run with the library's own communicator (RCCL), or -- every rank agreeing
+        through one all-reduce -- the fallback exchange through torch's collectives."""
+        if state["ctx"] is not None:
+            if dist is not None:
+                state["ctx"].comm_finalize()
+            state["ctx"].close()
+        ctx = capi.Context(device=local_rank, search=search, profile=profile)
+        state["ctx"] = ctx
+        if dist is None:
+            return ctx
         if args.rehearse_gloo:
             icpdist.init_callbacks(ctx, dist)
-        else:
-            # the library's own RCCL communicator; if it cannot be formed on some rank, every rank
-            # (they agree through one all-reduce) falls back to exchanging through torch's collectives
-            ok = 1.0
-            try:
-                if args.force_fallback_exchange:
-                    raise capi.IcpError(capi.ERR_RCCL, "--force-fallback-exchange")
-                icpdist.init_rccl(ctx, dist, device=dev, allow_single=args.force_dist)
-            except capi.IcpError as e:
-                sys.stderr.write("rank %d: library communicator failed (%s)\n" % (rank, e))
-                ok = 0.0
-            agreed = torch.tensor([ok], dtype=torch.float64, device=dev)
-            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-            if float(agreed.item()) < 1.0:
-                exchange = "torch.distributed collectives staged through device tensors (the library's RCCL communicator could not be formed)"
-                ctx.comm_finalize()
-                icpdist.init_callbacks(ctx, dist, device=dev)
+            return ctx
+        ok = 1.0
+        try:
+            if args.force_fallback_exchange:
+                raise capi.IcpError(capi.ERR_RCCL, "--force-fallback-exchange")
+            icpdist.init_rccl(ctx, dist, device=dev, allow_single=args.force_dist)
+        except capi.IcpError as e:
+            sys.stderr.write("rank %d: library communicator failed (%s)\n" % (rank, e))
+            ok = 0.0
+        agreed = torch.tensor([ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if float(agreed.item()) < 1.0:
+            state["exchange"] = ("torch.distributed collectives staged through device tensors (the library's RCCL "
+                                 "communicator could not be formed)")
+            ctx.comm_finalize()
+            icpdist.init_callbacks(ctx, dist, device=dev)
+        return ctx
 
     def call(iters):
         cfg = capi.Context.make_config(max_iterations=iters, tolerance=0.0, min_error=0.0)
-        return ctx.align_device(d_src.data_ptr(), hi - lo, d_tgt.data_ptr(), tgt.shape[0], cfg)
+        return state["ctx"].align_device(d_src.data_ptr(), hi - lo, d_tgt.data_ptr(), tgt.shape[0], cfg)
 
     def fence():
         torch.cuda.synchronize()
@@ -252,50 +305,99 @@ def main():
             times.append(el)
         return out, times
 
-    if args.warmup > 0:
-        call(args.warmup)
-    ctx.reset_profile()
-    (res, hist), call_times = timed_calls(args.repeats)
+    def series(search):
+        """warm-up call, then `--repeats` timed calls on a fresh context of engine `search` (profile level 1: HIP events
+        around the call, the loop, every 4th launch of the dominant kernel and every 4th all-reduce; the fp64 engine has
+        no single dominant kernel: level 2 times its whole search pass)"""
+        ctx = open_ctx(search, 2 if search == 1 else 1)
+        if args.warmup > 0:
+            call(args.warmup)
+        ctx.reset_profile()
+        (res, hist), times = timed_calls(args.repeats)
+        return res, hist, times, ctx.get_profile()
+
+    def comm_block(prof):
+        """Who the communicator says took part (icpmi_comm_info: ncclCommCount / UserRank / CuDevice, every rank's device
+        and PCI bus id gathered through the library's own all-gather) and what one all-reduce of a pass costs."""
+        if dist is None:
+            return None
+        info = state["ctx"].comm_info()   # (a collective: every rank calls it)
+        n_ex = int(prof["exchange_launches"])
+        return {"kind": info["kind"], "n_ranks": info["n_ranks"], "rank_of_reporter": info["rank"],
+                "devices": info["devices"], "pci_bus_ids": info["pci_bus_ids"],
+                "distinct_gpus": len(set(info["pci_bus_ids"])),
+                "allreduce_ms_per_pass": prof["exchange_ms"] / n_ex if n_ex else None,
+                "allreduces_timed": n_ex,
+                "how": "HIP events on the library's stream around ncclAllReduce of 30 doubles, every 4th pass of the timed calls"}
+
+    def culled_roofline(prof, n_local, m):
+        """The default engine's dominant kernel: the coarse pass over the (64-row group, split) pairs within reach.
+        Its work is the EXECUTED pairs (what the box test leaves), priced like the all-pairs kernel's."""
+        if not prof["coarse_launches"] or not prof["bounded_launches"]:
+            return None
+        k_ms = prof["coarse_ms"] / prof["coarse_launches"]
+        pairs_run = prof["nn_group_pairs_run"] * 64.0 * 2048.0 / max(1, prof["bounded_launches"])   # per launch
+        pairs_all = float(n_local) * float(m)
+        ach = FLOP_PER_PAIR * pairs_run / (k_ms * 1e-3) / 1e12
+        return {"kernel": "k_nn_coarse_groups (bf16 MFMA over the (64-row group, 2048-target split) pairs whose boxes are "
+                          "within the group's bound of each other)",
+                "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                "traffic": None, "avg_launch_ms": k_ms, "launches_timed": int(prof["coarse_launches"]),
+                "executed_pairs_per_launch": pairs_run, "all_pairs_per_launch": pairs_all,
+                "pairs_culled_frac": 1.0 - prof["nn_group_pairs_run"] / max(1, prof["nn_group_pairs"]),
+                "flop_per_launch": FLOP_PER_PAIR * pairs_run,
+                "equivalent_all_pairs_tflops": FLOP_PER_PAIR * pairs_all / (k_ms * 1e-3) / 1e12,
+                "note": "achieved = 8 flop x EXECUTED pairs / the kernel's average launch; equivalent_all_pairs_tflops prices the "
+                        "same launch as if it had evaluated every pair (what it makes unnecessary)"}
+
+    res, hist, call_times, prof = series(value_search)
     elapsed = float(np.median(call_times))
-    prof = ctx.get_profile()
     assert res.loop_iterations == args.steps, (res.loop_iterations, args.steps)
+    comm = comm_block(prof)
     # per-stage breakdown from a second, untimed call with every stage bracketed by events.
     # Single-GPU runs only: the multi-rank line carries nothing that needs a second communicator.
     stage = None
     if dist is None:
-        ctx.close()
-        ctx = capi.Context(device=local_rank, search=args.search, profile=2)
+        ctx = open_ctx(value_search, 2)
         call(args.steps)
         ctx.reset_profile()
         call(args.steps)
         stage = ctx.get_profile()
 
-    # extra: the opt-in pruned engine (ICPMI_SEARCH_MFMA_PRUNED) on the same job, same timing
-    # protocol.  Reported beside `value`, never as `value`: it is not an all-pairs pass.
-    pruned = None
-    if dist is None and not args.no_pruned_extra and args.search in (0, 2):
-        ctx.close()
-        ctx = capi.Context(device=local_rank, search=capi.SEARCH_MFMA_PRUNED, profile=1)
-        if args.warmup > 0:
-            call(args.warmup)
-        ctx.reset_profile()
-        (pres, phist), ptimes = timed_calls(args.repeats)
-        pel = float(np.median(ptimes))
-        pp = ctx.get_profile()
-        pruned = {"value": args.steps / pel, "unit": "ICP iterations/s", "ms_per_step": 1e3 * pel / args.steps,
-                  "steady_state_it_per_s": (args.steps + 1) * len(ptimes) / (pp["loop_ms"] * 1e-3) if pp["loop_ms"] > 0 else None,
-                  "units_culled_frac": pp["nn_pruned_blocks"] / max(1, pp["nn_coarse_blocks"]),
-                  "coarse_avg_launch_ms": pp["coarse_ms"] / max(1, pp["coarse_launches"]),
-                  "pose_delta_vs_all_pairs": list(synth.pose_delta(np.array(pres.transformation[:]).reshape(4, 4),
-                                                                   np.array(res.transformation[:]).reshape(4, 4))),
-                  "history_max_abs_diff": float(np.abs(np.asarray(phist) - np.asarray(hist)).max()),
-                  "note": "opt-in ICPMI_SEARCH_MFMA_PRUNED: same correspondences, (512-query block, 2048-target "
-                          "split) units culled by a bounding-box test against the previous iteration's distances"}
+    # The library's DEFAULT engine (ICPMI_SEARCH_AUTO: the culled search on a target of this size) on the same job, same
+    # timing protocol.  Reported beside `value` (the all-pairs engine, comparable with earlier rounds), with its own
+    # roofline on the pairs it executes; same correspondences, so history and pose must be the all-pairs run's.
+    default_engine = None
+    if not args.no_default_engine and value_search != 0:
+        try:
+            dres, dhist, dtimes, dprof = series(capi.SEARCH_AUTO)
+            del_ = float(np.median(dtimes))
+            n_local, m = hi - lo, tgt.shape[0]
+            culled = dprof["nn_group_pairs"] > 0
+            default_engine = {
+                "search": "ICPMI_SEARCH_AUTO -> " + ("culled MFMA search (nn_culled.h)" if culled else "the same engine as `value`"),
+                "value": args.steps / del_, "unit": "ICP iterations/s", "ms_per_step": 1e3 * del_ / args.steps,
+                "call_ms": {"median": 1e3 * del_, "min": 1e3 * min(dtimes), "max": 1e3 * max(dtimes), "samples": len(dtimes)},
+                "steady_state_it_per_s": (args.steps + 1) * len(dtimes) / (dprof["loop_ms"] * 1e-3) if dprof["loop_ms"] > 0 else None,
+                "vs_value": (args.steps / del_) / (args.steps / elapsed),
+                "roofline": culled_roofline(dprof, n_local, m),
+                "num_iterations_equal": bool(dres.num_iterations == res.num_iterations),
+                "pose_delta_vs_all_pairs": list(synth.pose_delta(np.array(dres.transformation[:]).reshape(4, 4),
+                                                                 np.array(res.transformation[:]).reshape(4, 4))),
+                "history_max_abs_diff": float(np.abs(np.asarray(dhist) - np.asarray(hist)).max()),
+                "history_bit_equal": bool(np.array_equal(np.asarray(dhist), np.asarray(hist))),
+                "comm": comm_block(dprof),
+                "note": "same correspondences as the all-pairs pass (the reference's own search culls too: kdtree.hpp:139,177); "
+                        "(row group, split) pairs culled by a bounding-box test against each row's bound -- the previous "
+                        "match's exact distance, in a call's first pass the nearest sorted target around the row's Morton place"}
+        except Exception as e:  # noqa: BLE001  (the headline must not depend on the second series)
+            default_engine = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         n_local, m = hi - lo, tgt.shape[0]
         mfma = prof["coarse_launches"] > 0
-        # dominant kernel: k_nn_coarse (bf16 MFMA engine) or the whole fp64 pass (exact engine)
+        culled_value = prof["nn_group_pairs"] > 0   # (--search 0 or 3: `value` itself is the culled engine)
+        # dominant kernel: the coarse pass (bf16 MFMA engines) or the whole fp64 pass (exact engine)
         k_ms = prof["coarse_ms"] / prof["coarse_launches"] if mfma else prof["nn_ms"] / max(prof["nn_launches"], 1)
         nn_avg_ms = stage["nn_ms"] / max(stage["nn_launches"], 1) if stage else None
         flops = FLOP_PER_PAIR * n_local * m
@@ -304,12 +406,34 @@ def main():
         # measured now, in child processes (this process keeps its own GPU context; the children are
         # started, not exec'ed): see measure_traffic
         traffic_info = None
-        if mfma and dist is None and not args.no_traffic:
-            ctx.close()
-            traffic_info = measure_traffic(args.points, args.search)
-            ctx = capi.Context(device=local_rank, search=args.search)
+        if mfma and not culled_value and dist is None and not args.no_traffic:
+            state["ctx"].close()
+            state["ctx"] = None
+            traffic_info = measure_traffic(args.points, value_search)
         traffic = traffic_info["hbm_bytes_per_launch"] if traffic_info else None
         algo_bytes = 24 * n_local + 24 * m + 4 * n_local
+        if culled_value:
+            roofline = culled_roofline(prof, n_local, m)
+        else:
+            roofline = {
+                "kernel": "k_nn_coarse_bounded (bf16 MFMA, all %dx%d pairs; every pass of the call)" % (n_local, m)
+                if mfma else "k_nn_f64",
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": traffic, "traffic_measurement": traffic_info,
+                "launches_timed": int(prof["coarse_launches"]) if mfma else int(prof["nn_launches"]),
+                "flop_per_launch": flops, "avg_launch_ms": k_ms,
+                # what the pipe actually executes: one 32x32x16 MFMA (32,768 flop) per 1024 pairs
+                "executed_mfma_tflops": (n_local * m / 1024.0) * 32768.0 / (k_ms * 1e-3) / 1e12 if mfma else None,
+                "achieved_vs_fp32_vector_peak": achieved / PEAK_FP32_TFLOPS,
+                "nn_pass_ms": nn_avg_ms,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                # the north_star's "achieved HBM GB/s": from the MEASURED bytes when the counter passes ran,
+                # the algorithmic figure (SURVEY 8d: 24N + 24M + 4N) beside it under its own name
+                "achieved_hbm_GBps": (traffic if traffic else algo_bytes) / (k_ms * 1e-3) / 1e9,
+                "achieved_hbm_GBps_basis": "measured traffic" if traffic else "algorithmic bytes (no counter pass)",
+                "algorithmic_hbm_GBps": algo_bytes / (k_ms * 1e-3) / 1e9,
+                "hbm_peak_GBps": 8000.0,
+            }
         out = {
             "metric": "ICP iterations/sec (100k->100k pts)",
             "value": args.steps / elapsed,
@@ -329,11 +453,12 @@ def main():
                        "source_points": int(src.shape[0]), "target_points": int(m),
                        "parallelism": ("source sharded x%d, REHEARSAL (not a scaling number): ranks share GPUs, "
                                        "exchange through gloo host callbacks" % world) if args.rehearse_gloo
-                       else "source sharded x%d, 30-double all-reduce/iter: %s" % (world, exchange or "RCCL inside the library")
+                       else "source sharded x%d, 30-double all-reduce/iter: %s" % (world, state["exchange"] or "RCCL inside the library")
                        if dist is not None else "single GPU",
-                       "search": "bf16 MFMA coarse pass over all pairs + exact fp64 resolve (certified after the pass in a call's "
-                                 "first iteration, behind the previous matches' distances from the second on)" if mfma
-                       else "exact fp64 brute force"},
+                       "search": ("culled bf16 MFMA search (nn_culled.h) + exact fp64 resolve" if culled_value else
+                                  "bf16 MFMA coarse pass over all pairs + exact fp64 resolve of the slots listed under each row's bound "
+                                  "(the previous match's distance; in the first pass the nearest sorted target around the row's Morton place)")
+                       if mfma else "exact fp64 brute force"},
             "steady_state_it_per_s": (args.steps + 1) * len(call_times) / (prof["loop_ms"] * 1e-3) if prof["loop_ms"] > 0 else None,
             "stage_ms_untimed_call": {k: stage[k] for k in ("nn_ms", "coarse_ms", "reduce_ms", "transform_ms",
                                                             "normals_ms", "setup_ms", "loop_ms", "total_ms")}
@@ -341,26 +466,9 @@ def main():
             "resolve_counters": {k: stage[k] for k in ("nn_recheck_queries", "nn_fallback_queries", "knn_fallback_rows")}
             if stage else None,
             "final_error": res.final_error,
-            "pruned_engine_extra": pruned,
-            "roofline": {
-                "kernel": "k_nn_coarse_bounded (k_nn_coarse<0> in a call's first pass; bf16 MFMA, all %dx%d pairs)" % (n_local, m)
-                if mfma else "k_nn_f64",
-                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": traffic, "traffic_measurement": traffic_info,
-                "launches_timed": int(prof["coarse_launches"]) if mfma else int(prof["nn_launches"]),
-                "flop_per_launch": flops, "avg_launch_ms": k_ms,
-                # what the pipe actually executes: one 32x32x16 MFMA (32,768 flop) per 1024 pairs
-                "executed_mfma_tflops": (n_local * m / 1024.0) * 32768.0 / (k_ms * 1e-3) / 1e12 if mfma else None,
-                "achieved_vs_fp32_vector_peak": achieved / PEAK_FP32_TFLOPS,
-                "nn_pass_ms": nn_avg_ms,
-                "algorithmic_bytes_per_launch": algo_bytes,
-                # the north_star's "achieved HBM GB/s": from the MEASURED bytes when the counter passes ran,
-                # the algorithmic figure (SURVEY 8d: 24N + 24M + 4N) beside it under its own name
-                "achieved_hbm_GBps": (traffic if traffic else algo_bytes) / (k_ms * 1e-3) / 1e9,
-                "achieved_hbm_GBps_basis": "measured traffic" if traffic else "algorithmic bytes (no counter pass)",
-                "algorithmic_hbm_GBps": algo_bytes / (k_ms * 1e-3) / 1e9,
-                "hbm_peak_GBps": 8000.0,
-            },
+            "rccl": comm,
+            "default_engine": default_engine,
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline and dist is None:
             cb = cpu_baseline(src, tgt, args.cpu_steps or args.steps)
@@ -375,8 +483,7 @@ def main():
                 # GPU through the C ABI vs the oracle's kd-tree, and the normals of the target
                 from oracle import oracle as orc
                 nth = os.cpu_count() or 1
-                ctx.close()
-                ctx = capi.Context(device=local_rank, search=args.search)   # the engine `value` was measured with
+                ctx = open_ctx(value_search, 0)   # the engine `value` was measured with
                 gi, gd = ctx.nearest_batch(tgt, src)
                 oi, od = orc.KDTree(tgt).nearest_batch(src, nthreads=nth)
                 out["parity"]["nn_index_mismatches"] = int((gi != oi).sum())
@@ -387,7 +494,10 @@ def main():
             out["speedup_vs_cpu_1thread"] = out["value"] / cb["value"]
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    ctx.close()
+    if state["ctx"] is not None:
+        if dist is not None:
+            state["ctx"].comm_finalize()
+        state["ctx"].close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

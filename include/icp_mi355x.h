@@ -53,9 +53,11 @@ extern "C" {
 #define ICPMI_SEARCH_AUTO 0
 #define ICPMI_SEARCH_EXACT_F64 1     /* fp64 brute force, SGPR-broadcast targets */
 #define ICPMI_SEARCH_MFMA_BF16 2     /* bf16 MFMA coarse pass over ALL pairs + certified fp64 resolve */
-#define ICPMI_SEARCH_MFMA_PRUNED 3   /* the same, skipping (query block, target split) pairs whose bounding
-                                        boxes are farther apart than the block's known neighbour distance;
-                                        same exact result, not an all-pairs pass (icpmi_align* only) */
+#define ICPMI_SEARCH_MFMA_PRUNED 3   /* the same, skipping (64-row group, target split) pairs whose bounding
+                                        boxes are farther apart than the group's known neighbour distance -- the
+                                        rule of kdtree.hpp:139,177 applied to groups; same exact result, not an
+                                        all-pairs pass (registrations and normal estimation).  AUTO takes it for
+                                        targets of more than 16 splits (32,768 points), engine 2 below that */
 
 typedef struct icpmi_ctx icpmi_ctx;
 
@@ -104,7 +106,10 @@ typedef struct {
     int64_t nn_coarse_blocks;                        /* (512-query block, 2048-target split) workgroups launched */
     int64_t nn_pruned_blocks;                        /* of those, skipped by ICPMI_SEARCH_MFMA_PRUNED's box test */
     int64_t small_launches;                          /* iterations run by the small-cloud kernel (search + residuals + pose update in one launch) */
-    int64_t bounded_launches;                        /* passes of the ICP loop searched behind the previous pass's matches (lists instead of coarse minima) */
+    int64_t bounded_launches;                        /* passes of the ICP loop searched behind a bound per row (lists instead of coarse minima) */
+    int64_t nn_group_pairs;                          /* culled engine: (64-row group, 2048-target split) pairs of its passes ... */
+    int64_t nn_group_pairs_run;                      /* ... and those within reach, the ones the coarse pass evaluated */
+    double exchange_ms;  int64_t exchange_launches;  /* sharded runs: the per-pass all-reduce of 30 doubles alone (the launches bracketed) */
 } icpmi_profile;
 
 void icpmi_options_default(icpmi_options *opt);     /* device 0, normal_k 20 (icp.hpp:170), search AUTO or the
@@ -343,6 +348,19 @@ typedef int (*icpmi_allgather_fn)(void *user, double *buf, int32_t count_per_ran
 int icpmi_comm_init_callbacks(icpmi_ctx *ctx, int32_t n_ranks, int32_t rank,
                               icpmi_allreduce_fn allreduce, icpmi_allgather_fn allgather,
                               void *user);
+
+/* Who is in this context's communicator, asked of the communicator itself (new, like the rest of the multi-GPU
+ * section: no reference counterpart): n_ranks / rank / this rank's device from ncclCommCount / ncclCommUserRank /
+ * ncclCommCuDevice, and every rank's device ordinal and PCI bus id gathered through the library's own all-gather --
+ * so that a scaling line can prove how many distinct GPUs its ranks ran on.  A collective: every rank calls it.
+ * kind: 0 no communicator (n_ranks 1), 1 RCCL, 2 host callbacks (n_ranks as given to icpmi_comm_init_callbacks). */
+#define ICPMI_MAX_RANKS_INFO 64
+typedef struct {
+    int32_t kind, n_ranks, rank, reserved;
+    int32_t device[ICPMI_MAX_RANKS_INFO];
+    char pci_bus_id[ICPMI_MAX_RANKS_INFO][16];
+} icpmi_comm_info_t;
+int icpmi_comm_info(icpmi_ctx *ctx, icpmi_comm_info_t *out);
 
 /* profiling */
 int icpmi_reset_profile(icpmi_ctx *ctx);

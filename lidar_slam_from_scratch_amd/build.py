@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libicp_mi355x.so")
-_SOURCES = ["capi.hip", "sort.hip", "kernels.h", "device_math.h", "nn_mfma.h", "icp_small.h", "knn_lists.h", "nn_bounded.h", "voxel.h", "scan_context.h", "occupancy.h", "Makefile"]
+_SOURCES = ["capi.hip", "sort.hip", "kernels.h", "device_math.h", "nn_mfma.h", "icp_small.h", "knn_lists.h", "nn_bounded.h", "nn_culled.h", "voxel.h", "scan_context.h", "occupancy.h", "Makefile"]
 
 
 def _stale():

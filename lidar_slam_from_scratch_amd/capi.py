@@ -21,7 +21,7 @@ EXPORTS = [
     "icpmi_destroy", "icpmi_last_error", "icpmi_align", "icpmi_align_device", "icpmi_align_batch",
     "icpmi_nearest_batch", "icpmi_k_nearest", "icpmi_estimate_normals", "icpmi_solve_point_to_plane",
     "icpmi_transform_points", "icpmi_comm_unique_id", "icpmi_comm_init", "icpmi_comm_finalize",
-    "icpmi_comm_init_callbacks", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
+    "icpmi_comm_init_callbacks", "icpmi_comm_info", "icpmi_voxel_downsample", "icpmi_voxel_downsample_device",
     "icpmi_scan_context", "icpmi_scan_context_distances", "icpmi_load_cloud", "icpmi_load_cloud_device",
     "icpmi_upload_points_f32", "icpmi_discover_frames", "icpmi_estimate_normals_rows",
     "icpmi_stream_push", "icpmi_stream_push_host", "icpmi_stream_push_file", "icpmi_stream_prefetch_file", "icpmi_stream_reset",
@@ -59,7 +59,19 @@ class Profile(C.Structure):
                 ("nn_pairs", C.c_double), ("nn_recheck_queries", C.c_int64),
                 ("nn_fallback_queries", C.c_int64), ("knn_fallback_rows", C.c_int64),
                 ("nn_coarse_blocks", C.c_int64), ("nn_pruned_blocks", C.c_int64), ("small_launches", C.c_int64),
-                ("bounded_launches", C.c_int64)]
+                ("bounded_launches", C.c_int64),
+                ("nn_group_pairs", C.c_int64),
+                ("nn_group_pairs_run", C.c_int64),
+                ("exchange_ms", C.c_double), ("exchange_launches", C.c_int64)]
+
+
+MAX_RANKS_INFO = 64
+MAX_BATCH = 8   # ICPMI_MAX_BATCH
+
+
+class CommInfo(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_ranks", C.c_int32), ("rank", C.c_int32), ("reserved", C.c_int32),
+                ("device", C.c_int32 * MAX_RANKS_INFO), ("pci_bus_id", (C.c_char * 16) * MAX_RANKS_INFO)]
 
 
 class StreamInfo(C.Structure):
@@ -190,6 +202,7 @@ def load_library(path=None):
     L.icpmi_comm_init.argtypes = [vp, C.c_int32, C.c_int32, vp]
     L.icpmi_comm_finalize.argtypes = [vp]
     L.icpmi_comm_init_callbacks.argtypes = [vp, C.c_int32, C.c_int32, ALLREDUCE_FN, ALLGATHER_FN, vp]
+    L.icpmi_comm_info.argtypes = [vp, C.POINTER(CommInfo)]
     L.icpmi_reset_profile.argtypes = [vp]
     L.icpmi_get_profile.argtypes = [vp, C.POINTER(Profile)]
     for name in EXPORTS:
@@ -554,6 +567,15 @@ class Context:
     def comm_finalize(self):
         self._check(self._lib.icpmi_comm_finalize(self._h))
         self.n_ranks, self.rank = 1, 0
+
+    def comm_info(self):
+        """icpmi_comm_info (a collective): the communicator's own size and rank, every rank's device and PCI bus id."""
+        ci = CommInfo()
+        self._check(self._lib.icpmi_comm_info(self._h, C.byref(ci)))
+        n = ci.n_ranks
+        return {"kind": {0: "none", 1: "rccl", 2: "callbacks"}[ci.kind], "n_ranks": n, "rank": ci.rank,
+                "devices": [int(ci.device[r]) for r in range(n)],
+                "pci_bus_ids": [bytes(ci.pci_bus_id[r]).split(b"\0")[0].decode() for r in range(n)]}
 
     def reset_profile(self):
         self._check(self._lib.icpmi_reset_profile(self._h))

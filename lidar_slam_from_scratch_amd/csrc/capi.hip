@@ -34,6 +34,7 @@
 #include "icp_small.h"
 #include "knn_lists.h"
 #include "nn_bounded.h"
+#include "nn_culled.h"
 #include "voxel.h"
 #include "scan_context.h"
 #include "occupancy.h"
@@ -73,7 +74,7 @@ struct EventPair {
     int stage;
 };
 
-enum Stage { ST_NN = 0, ST_REDUCE = 1, ST_TRANSFORM = 2, ST_NORMALS = 3, ST_TOTAL = 4, ST_LOOP = 5, ST_SETUP = 6, ST_COARSE = 7 };
+enum Stage { ST_NN = 0, ST_REDUCE = 1, ST_TRANSFORM = 2, ST_NORMALS = 3, ST_TOTAL = 4, ST_LOOP = 5, ST_SETUP = 6, ST_COARSE = 7, ST_EXCHANGE = 8 };
 
 // roctx ranges around the stages of a call (SURVEY section 5 "Tracing"): visible to
 // `rocprofv3 --marker-trace`.  The library is looked up at run time (the rocprofiler-sdk's roctx
@@ -117,6 +118,9 @@ struct Rccl {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
 };
 
 } // namespace
@@ -216,11 +220,13 @@ struct icpmi_ctx {
     long pushes = 0;
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
-    DevBuf src_sort, blk_lists, work;         // pruned engine: Morton order of the source, per-block split lists, unit list
-    bool nn_pruned = false;                   // ICPMI_SEARCH_MFMA_PRUNED requested (align calls only)
+    DevBuf src_sort;                          // Morton order of the source rows (the loop's internal order)
+    DevBuf grp_cnt, grp_items;                // culled engine: per target split the list of 64-row groups within reach (nn_culled.h)
+    bool nn_pruned = false;                   // the culled engine (ICPMI_SEARCH_MFMA_PRUNED; AUTO on large targets)
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
     int nn_splits = 0;
     int nn_ms = 0;                            // component stride of the SoA sorted target
+    int grp_cap = 0;                          // groups a split's list in grp_items can hold
     IcpState *d_state = nullptr;   // two of them (align_device alternates in the sharded loop)
     IcpState *h_state = nullptr;   // pinned
     double *h_hist = nullptr;      // pinned: the error history of the last call
@@ -234,6 +240,7 @@ struct icpmi_ctx {
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
     unsigned coarse_seen = 0;      // k_nn_coarse launches since the context was made (profile 1 samples them)
+    unsigned exchange_seen = 0;    // ... and the per-pass all-reduces of a sharded run
     icpmi_profile prof;
 
     // multi-GPU
@@ -308,11 +315,12 @@ struct StageTimer {
         // profile 1: only the dominant kernel and the call/loop brackets (3 event pairs per
         // iteration would already cost ~10 us of stream time); profile >= 2: every stage
         if (!ctx->opt.profile) return;
-        if (ctx->opt.profile == 1 && stage != ST_COARSE && stage != ST_TOTAL && stage != ST_LOOP) return;
+        if (ctx->opt.profile == 1 && stage != ST_COARSE && stage != ST_TOTAL && stage != ST_LOOP && stage != ST_EXCHANGE) return;
         // profile 1 brackets the dominant kernel on every 4th launch only: an event pair costs the
         // stream ~5 us, and on every launch that was 2.2 % of a C3 call (scripts/event_overhead.py);
         // the average over the sampled launches is the same number
         if (ctx->opt.profile == 1 && stage == ST_COARSE && (ctx->coarse_seen++ & 3) != 0) return;
+        if (ctx->opt.profile == 1 && stage == ST_EXCHANGE && (ctx->exchange_seen++ & 3) != 0) return; // (the same sampling)
         if (ctx->ev_used == ctx->ev_pool.size()) {
             EventPair p;
             if (hipEventCreate(&p.a) != hipSuccess) return;
@@ -360,6 +368,7 @@ void harvest_profile(icpmi_ctx *ctx)
         case ST_LOOP: ctx->prof.loop_ms += ms; break;
         case ST_SETUP: ctx->prof.setup_ms += ms; break;
         case ST_COARSE: ctx->prof.coarse_ms += ms; ctx->prof.coarse_launches++; break;
+        case ST_EXCHANGE: ctx->prof.exchange_ms += ms; ctx->prof.exchange_launches++; break;
         default: break;
         }
     }
@@ -451,22 +460,37 @@ bool small_target(const icpmi_ctx *ctx)
 // Choose and prepare the search engine for a target cloud (once per call: the target does
 // not move).  Both engines return the same indices; AUTO takes the MFMA engine once the
 // pair count makes its fixed costs (Morton sort, operand packing, resolve) worthwhile.
+// AUTO: the exact fp64 kernels for tiny clouds; the MFMA engine from 256 targets -- over all pairs while the target is
+// the handful of splits the small-cloud kernel takes (icp_small.h), culled (nn_culled.h) beyond: the same correspondences
+// bit for bit, 84-95 % of the (row group, split) pairs never evaluated (round 4; ICPMI_AUTO_CULLED=0 keeps AUTO on the
+// all-pairs engine everywhere, the A/B knob).
+bool auto_culled_enabled()
+{
+    static const bool v = [] {
+        const char *e = getenv("ICPMI_AUTO_CULLED");
+        return !(e && e[0] == '0' && e[1] == '\0');
+    }();
+    return v;
+}
 int engine_for(const icpmi_ctx *ctx, int m, int n_hint)
 {
     int engine = ctx->opt.search;
-    if (engine == ICPMI_SEARCH_AUTO)
+    const int splits = (m + kSplitTargets - 1) / kSplitTargets;
+    if (engine == ICPMI_SEARCH_AUTO) {
         engine = (m >= mfma_min_targets() && n_hint >= kMfmaMinQueries) ? ICPMI_SEARCH_MFMA_BF16 : ICPMI_SEARCH_EXACT_F64;
+        if (engine == ICPMI_SEARCH_MFMA_BF16 && splits > kSmallMaxSplits && auto_culled_enabled()) engine = ICPMI_SEARCH_MFMA_PRUNED;
+    }
+    // (the culled coarse kernel keeps a running sum over the splits in LDS: beyond kCullMaxSplits -- 8.4M targets -- all pairs)
+    if (engine == ICPMI_SEARCH_MFMA_PRUNED && splits > kCullMaxSplits) engine = ICPMI_SEARCH_MFMA_BF16;
     return engine;
 }
 
 int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
 {
     ctx->prep_valid = false; // whatever target the buffers held: it is being replaced
-    int engine = ctx->opt.search;
-    if (engine == ICPMI_SEARCH_AUTO)
-        engine = (m >= mfma_min_targets() && n_hint >= kMfmaMinQueries) ? ICPMI_SEARCH_MFMA_BF16 : ICPMI_SEARCH_EXACT_F64;
-    // the pruned engine is the MFMA engine plus block/split culling inside the ICP loop; the
-    // stand-alone searches (nearest_batch, normals) have no previous neighbour to bound with
+    int engine = engine_for(ctx, m, n_hint);
+    // the culled engine is the MFMA engine plus the box test of (row group, split) pairs in the ICP loop and in normal
+    // estimation; the stand-alone 1-NN search (nearest_batch) runs over all pairs
     ctx->nn_pruned = engine == ICPMI_SEARCH_MFMA_PRUNED;
     if (ctx->nn_pruned) engine = ICPMI_SEARCH_MFMA_BF16;
     ctx->nn_engine = engine;
@@ -594,6 +618,47 @@ NnListRows nn_list_rows(const icpmi_ctx *ctx, int n)
     return r;
 }
 
+// The culled engine's group lists (nn_culled.h) inside ctx->grp_cnt / grp_items: two alternating sets of per-split counters
+// (a pass reads one and clears the other), one array of lists, and two statistics words behind the counters.
+constexpr int kGrpCntPad = 64;
+int reserve_group_lists(icpmi_ctx *ctx, int splits, long groups)
+{
+    int rc;
+    const size_t per = ((size_t)splits + kGrpCntPad - 1) / kGrpCntPad * kGrpCntPad;
+    if ((rc = reserve(ctx, ctx->grp_cnt, sizeof(unsigned) * 2 * per + 2 * sizeof(unsigned long long)))) return rc;
+    if ((rc = reserve(ctx, ctx->grp_items, sizeof(unsigned) * (size_t)splits * (size_t)std::max<long>(groups, 1)))) return rc;
+    ctx->grp_cap = (int)std::max<long>(groups, 1);
+    return ICPMI_OK;
+}
+GroupLists group_lists(const icpmi_ctx *ctx, int set)
+{
+    const size_t per = ((size_t)ctx->nn_splits + kGrpCntPad - 1) / kGrpCntPad * kGrpCntPad;
+    return GroupLists{(unsigned *)ctx->grp_cnt.p + (size_t)set * per, (unsigned *)ctx->grp_items.p, ctx->grp_cap};
+}
+unsigned long long *group_stats(const icpmi_ctx *ctx)
+{
+    const size_t per = ((size_t)ctx->nn_splits + kGrpCntPad - 1) / kGrpCntPad * kGrpCntPad;
+    return (unsigned long long *)((unsigned *)ctx->grp_cnt.p + 2 * per);
+}
+size_t group_cnt_bytes(const icpmi_ctx *ctx)
+{
+    const size_t per = ((size_t)ctx->nn_splits + kGrpCntPad - 1) / kGrpCntPad * kGrpCntPad;
+    return sizeof(unsigned) * 2 * per + 2 * sizeof(unsigned long long);
+}
+// workgroups of k_nn_coarse_groups: the chip's resident set (two 8-wave workgroups per CU at 4 waves per SIMD); a
+// workgroup walks over the chunks blockIdx, blockIdx + grid, ...  ICPMI_GROUPS_GRID=<per CU> for tuning runs.
+int coarse_groups_grid(const icpmi_ctx *ctx)
+{
+    static const int per_cu = [] {
+        if (const char *e = getenv("ICPMI_GROUPS_GRID")) {
+            const long x = strtol(e, nullptr, 10);
+            if (x >= 1 && x <= 64) return (int)x;
+        }
+        return 2;
+    }();
+    return per_cu * ctx->cu_count;
+}
+
 // `bounded`: d_idx holds the rows' matches of the previous pass and the kernel that moved the rows has left their bounds
 // in ctx->nn_lists (RowBounds, kernels.h; nn_bounded.h)
 int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx, double *d_d2,
@@ -617,15 +682,15 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
             StageTimer tc(ctx, ST_COARSE);
             const KnnLists kl{ubf_row, sqf_row, cnt_row, ent_row, kNnEntCap};
             if (pruned_pass >= 0) {
-                // the pruned engine's surviving units, list epilogue: a row's list then holds slots of evaluated splits only,
-                // and every split that can hold a target within the row's bound IS evaluated (the block's bound is the
-                // largest of its rows')
-                unsigned *cnt = (unsigned *)((char *)ctx->nn_misc.p + 160);
-                hipLaunchKernelGGL((k_nn_coarse_list<2, false, kCoarseQT, kCoarseWaves>), dim3(2 * ctx->cu_count), dim3(kCoarseThreads), 0,
-                                   ctx->stream, d_qry, n, (size_t)0, (const uint4 *)ctx->bpack.p, frames, (float2 *)nullptr,
-                                   (float *)nullptr, splits, (const unsigned *)ctx->work.p, (const unsigned *)(cnt + (pruned_pass & 1)),
-                                   cnt + ((pruned_pass + 1) & 1), (unsigned)(((n + kCoarseQueries - 1) / kCoarseQueries) * splits),
-                                   counters + 2, st, kl);
+                // the culled engine's surviving (row group, split) pairs, list epilogue: a row's list then holds slots of
+                // evaluated splits only, and every split that can hold a target within the row's bound IS evaluated (the
+                // group's bound is the largest of its rows'); pass p reads the lists counted in set p & 1 and clears the other
+                const GroupLists cur = group_lists(ctx, pruned_pass & 1), nxt = group_lists(ctx, (pruned_pass + 1) & 1);
+                const long groups = (n + kGroupRows - 1) / kGroupRows;
+                hipLaunchKernelGGL((k_nn_coarse_groups<false, kCoarseWaves>), dim3(coarse_groups_grid(ctx)), dim3(kCoarseThreads), 0, ctx->stream,
+                                   d_qry, n, (size_t)0, (const uint4 *)ctx->bpack.p, frames, splits, (const unsigned *)cur.items, cur.cap,
+                                   (const unsigned *)cur.cnt, nxt.cnt, ctx->opt.profile ? group_stats(ctx) : (unsigned long long *)nullptr,
+                                   (unsigned long long)(groups * splits), st, kl);
             } else if (coarse_half_units(ctx, n, splits)) {
                 constexpr int per = kCoarseQueries / kCoarseQT; // queries per workgroup with one tile per wave
                 hipLaunchKernelGGL((k_nn_coarse_bounded<1, kCoarseWaves>), dim3((n + per - 1) / per, splits), dim3(kCoarseThreads), 0,
@@ -653,19 +718,11 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
         HIP_TRY(ctx, hipGetLastError());
         return ICPMI_OK;
     }
+    if (pruned_pass >= 0) return fail(ctx, ICPMI_ERR_ARG, "internal: the culled engine has bounded passes only");
     if ((rc = reserve(ctx, ctx->coarse, coarse_bytes(splits, n)))) return rc;
     {
         StageTimer tc(ctx, ST_COARSE); // the dominant kernel alone (matches rocprofv3's per-kernel average)
-        if (pruned_pass >= 0) {
-            // pass p consumes the list counted in work_cnt[p & 1] and clears the other counter
-            unsigned *cnt = (unsigned *)((char *)ctx->nn_misc.p + 160);
-            hipLaunchKernelGGL((k_nn_coarse_list<0, false, kCoarseQT, kCoarseWaves>), dim3(2 * ctx->cu_count), dim3(kCoarseThreads), 0,
-                               ctx->stream, d_qry, n, (size_t)0, (const uint4 *)ctx->bpack.p, frames, (float2 *)ctx->coarse.p,
-                               (float *)nullptr, splits,
-                               (const unsigned *)ctx->work.p, (const unsigned *)(cnt + (pruned_pass & 1)),
-                               cnt + ((pruned_pass + 1) & 1),
-                               (unsigned)(((n + kCoarseQueries - 1) / kCoarseQueries) * splits), counters + 2, st);
-        } else if (coarse_half_units(ctx, n, splits)) {
+        if (coarse_half_units(ctx, n, splits)) {
             constexpr int per = kCoarseQueries / kCoarseQT; // queries per workgroup with one tile per wave
             hipLaunchKernelGGL((k_nn_coarse<0, 1, kCoarseWaves>), dim3((n + per - 1) / per, splits), dim3(kCoarseThreads), 0,
                                ctx->stream, d_qry, n, (const uint4 *)ctx->bpack.p, frames, (float2 *)ctx->coarse.p,
@@ -677,8 +734,7 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
         }
         ctx->prof.nn_coarse_blocks += (int64_t)((n + kCoarseQueries - 1) / kCoarseQueries) * splits;
     }
-    const int *blk_cnt = pruned_pass >= 0 ? (const int *)ctx->blk_lists.p : nullptr;
-    const int *blk_list = blk_cnt ? blk_cnt + (n + kCoarseQueries - 1) / kCoarseQueries : nullptr;
+    const int *blk_cnt = nullptr, *blk_list = nullptr; // (round 3's per-block split lists: the culled engine no longer has unbounded passes)
 #define ICPMI_RESOLVE_ARGS                                                                                            \
     d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits, frames,  \
         (const NnFrame *)ctx->nn_misc.p, d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, blk_cnt, blk_list, st
@@ -783,7 +839,7 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
         }();
         // all-pairs engine, rows in the target's Morton order: bound first, lists instead of minima (knn_lists.h)
         // (pruned engine: the same lists on the units that survive the box test against the block's largest row bound)
-        const bool lists = by_sorted_row && (knn_lists_enabled() || !ctx->nn_pruned);
+        const bool lists = by_sorted_row; // (round 3's block lists over slot minima for the culled engine are gone)
         const bool lists_culled = lists && ctx->nn_pruned;
         // rows that are not a range of sorted positions (arbitrary queries: icpmi_k_nearest; rows by point index:
         // icpmi_estimate_normals_rows) get their place in the sorted order from their Morton key (k_knn_prebound_q)
@@ -798,17 +854,7 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
         HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, sizeof(int), s));
         const SplitFrame *frames = (const SplitFrame *)ctx->frames.p;
         const double *sorted = (const double *)ctx->tgt_sorted.p;
-        const int cblocks = (int)(chunk / kCoarseQueries);
-        int *blk_cnt = nullptr, *blk_list = nullptr;
-        unsigned *work = nullptr, *work_cnt = nullptr;
-        if (by_sorted_row && (!lists || lists_culled)) {
-            if ((rc = reserve(ctx, ctx->blk_lists, sizeof(int) * (size_t)cblocks * ((size_t)splits + 1)))) return rc;
-            if ((rc = reserve(ctx, ctx->work, sizeof(unsigned) * (size_t)cblocks * (size_t)splits))) return rc;
-            blk_cnt = (int *)ctx->blk_lists.p;
-            blk_list = blk_cnt + cblocks;
-            work = (unsigned *)ctx->work.p;
-            work_cnt = (unsigned *)((char *)ctx->nn_misc.p + 168);
-        }
+        if (lists_culled && (rc = reserve_group_lists(ctx, splits, chunk / kGroupRows))) return rc;
         for (long c0 = row0; c0 < row1; c0 += chunk) {
             const int nq = (int)std::min<long>(chunk, row1 - c0);
             const int nblk = (nq + kCoarseQueries - 1) / kCoarseQueries;
@@ -821,13 +867,16 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                 hipLaunchKernelGGL(k_knn_prebound, dim3((nq + kPreRows - 1) / kPreRows), dim3(256), 0, s, sorted, m, ctx->nn_ms, k, (int)c0, nq,
                                    t_row, tf_row, sqf_row, cnt_row);
                 if (lists_culled) {
-                    HIP_TRY(ctx, hipMemsetAsync(work_cnt, 0, sizeof(unsigned), s));
-                    hipLaunchKernelGGL(k_knn_block_bounds, dim3(nblk), dim3(kCoarseQueries), 0, s, sorted, m, ctx->nn_ms, (int)c0, nq,
-                                       std::min(k, 64), frames, splits, blk_cnt, blk_list, work, work_cnt, (const double *)t_row);
-                    hipLaunchKernelGGL((k_nn_coarse_list<2, true, kCoarseQT, kCoarseWaves>), dim3(2 * ctx->cu_count), dim3(kCoarseThreads),
-                                       0, s, sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, (float2 *)nullptr,
-                                       (float *)nullptr, splits, (const unsigned *)work, (const unsigned *)work_cnt,
-                                       (unsigned *)nullptr, 0u, (unsigned long long *)nullptr, (const IcpState *)nullptr, kl);
+                    // the groups are runs of 64 sorted rows, their bound the largest of their rows' (nn_culled.h)
+                    const GroupLists gl = group_lists(ctx, 0);
+                    const int groups = (nq + kGroupRows - 1) / kGroupRows;
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->grp_cnt.p, 0, group_cnt_bytes(ctx), s));
+                    hipLaunchKernelGGL(k_knn_group_cull, dim3((groups + 3) / 4), dim3(256), 0, s, sorted, m, ctx->nn_ms, (int)c0, nq,
+                                       (const double *)t_row, frames, splits, gl);
+                    hipLaunchKernelGGL((k_nn_coarse_groups<true, kCoarseWaves>), dim3(coarse_groups_grid(ctx)), dim3(kCoarseThreads), 0, s,
+                                       sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, splits,
+                                       (const unsigned *)gl.items, gl.cap, (const unsigned *)gl.cnt, (unsigned *)nullptr,
+                                       (unsigned long long *)nullptr, 0ull, (const IcpState *)nullptr, kl);
                 } else if (coarse_half_units(ctx, nq, splits)) {
                     constexpr int per = kCoarseQueries / kCoarseQT;
                     hipLaunchKernelGGL((k_nn_coarse_rows<1, kCoarseWaves>), dim3((nq + per - 1) / per, splits), dim3(kCoarseThreads), 0,
@@ -857,17 +906,6 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                 hipLaunchKernelGGL(k_knn_resolve_lists<true>, dim3((nq + 3) / 4), dim3(256), 0, s, d_qry, sorted, perm, m, ctx->nn_ms, k,
                                    (int)c0, nq, (const double *)t_row, (const int *)cnt_row, (const unsigned *)ent_row, knn, fb_list,
                                    fb_count);
-            } else if (by_sorted_row) {
-                HIP_TRY(ctx, hipMemsetAsync(work_cnt, 0, sizeof(unsigned), s));
-                hipLaunchKernelGGL(k_knn_block_bounds, dim3(nblk), dim3(kCoarseQueries), 0, s, sorted, m, ctx->nn_ms, (int)c0, nq,
-                                   std::min(k, 64), frames, splits, blk_cnt, blk_list, work, work_cnt);
-                hipLaunchKernelGGL((k_nn_coarse_list<1, true, kCoarseQT, kCoarseWaves>), dim3(2 * ctx->cu_count), dim3(kCoarseThreads),
-                                   0, s, sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, (float2 *)nullptr,
-                                   (float *)ctx->slotmin.p, splits, (const unsigned *)work, (const unsigned *)work_cnt,
-                                   (unsigned *)nullptr, 0u, (unsigned long long *)nullptr, (const IcpState *)nullptr);
-                hipLaunchKernelGGL(k_knn_resolve<true>, dim3((nq + 3) / 4), dim3(256), 0, s, d_pts, (int)c0, nq, sorted, perm, m,
-                                   ctx->nn_ms, k, (const float *)ctx->slotmin.p, nslots, frames, (const NnFrame *)ctx->nn_misc.p, knn,
-                                   fb_list, fb_count, (const int *)blk_cnt, (const int *)blk_list);
             } else {
                 if (coarse_half_units(ctx, nq, splits)) {
                     constexpr int per = kCoarseQueries / kCoarseQT;
@@ -961,6 +999,9 @@ int load_rccl(icpmi_ctx *ctx)
     SYM(AllReduce, "ncclAllReduce");
     SYM(AllGather, "ncclAllGather");
     SYM(GetErrorString, "ncclGetErrorString");
+    SYM(CommCount, "ncclCommCount");
+    SYM(CommUserRank, "ncclCommUserRank");
+    SYM(CommCuDevice, "ncclCommCuDevice");
 #undef SYM
     return ICPMI_OK;
 }
@@ -1151,9 +1192,6 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // blob whose bounding box can rule whole target splits out.  The order of the rows of
     // `cur` is internal: only sums over all rows leave this function.
     const bool pruned = fused && ctx->nn_pruned && n > 0;
-    const int qblocks = (n + kCoarseQueries - 1) / kCoarseQueries;
-    int *blk_cnt = nullptr, *blk_list = nullptr;
-    unsigned *work = nullptr, *work_cnt = nullptr;
     const SplitFrame *frames = (const SplitFrame *)ctx->frames.p;
     const int splits = ctx->nn_splits;
     int pass_no = 0; // coarse passes queued so far: selects the work counter (see k_nn_coarse_list)
@@ -1175,14 +1213,9 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         if ((rc = reserve(ctx, ctx->sort_tmp, sort_bytes))) return rc; // the target's sort is done (stream order)
         if ((rc = reserve(ctx, ctx->bbox_part, sizeof(double) * 6 * (size_t)bblocks))) return rc;
     }
-    if (pruned) {
-        if ((rc = reserve(ctx, ctx->blk_lists, sizeof(int) * (size_t)qblocks * ((size_t)splits + 1)))) return rc;
-        if ((rc = reserve(ctx, ctx->work, sizeof(unsigned) * (size_t)qblocks * (size_t)splits))) return rc;
-        blk_cnt = (int *)ctx->blk_lists.p;
-        blk_list = blk_cnt + qblocks;
-        work = (unsigned *)ctx->work.p;
-        work_cnt = (unsigned *)((char *)ctx->nn_misc.p + 160);
-        HIP_TRY(ctx, hipMemsetAsync(work_cnt, 0, 2 * sizeof(unsigned), s));
+    if (pruned) { // the group lists of the coming passes (nn_culled.h); both sets of counters start empty
+        if ((rc = reserve_group_lists(ctx, splits, (n + kGroupRows - 1) / kGroupRows))) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->grp_cnt.p, 0, group_cnt_bytes(ctx), s));
     }
     if (pruned || sorted_rows_loop) {
         const int bblocks = std::max(1, std::min(256, (n + 255) / 256));
@@ -1200,7 +1233,13 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
 
     // Bounded passes (nn_bounded.h): every kernel that moves the rows after a pass also leaves, per row, the exact distance
     // to the target it was just matched with -- the bound the next pass searches behind.
-    const bool bounded_loop = (sorted_rows_loop || (pruned && resolve_waves(n) != -32)) && nn_bounded_enabled();
+    // Round 4: the FIRST pass has a bound too -- the nearest of the sorted targets around each row's place in the target's
+    // Morton order (k_nn_prebound1) stands in for the previous match -- so no pass of a registration keeps coarse minima:
+    // the (row, split) buffer (6 B each: 2.9 GB at 1M x 1M) is not reserved by this function at all.  Every general-path
+    // loop of the MFMA engines is bounded now, whatever its row order (ICPMI_NN_BOUNDED=0: round 2's form for the
+    // all-pairs engine, the A/B and fuzz reference; the culled engine has no other form).
+    const bool bounded_loop = fused && !small && n > 0 && resolve_waves(n) != -32 && (pruned || nn_bounded_enabled());
+    if (pruned && !bounded_loop) return fail(ctx, ICPMI_ERR_ARG, "internal: the culled engine needs the bounded resolve kernels");
     RowBounds rb{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     if (bounded_loop) {
         if ((rc = reserve(ctx, ctx->nn_lists, kNnListRowBytes * (size_t)n + 64))) return rc;
@@ -1211,13 +1250,12 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // current_source = source * R0^T + t0^T (icp.hpp:174-176)
     if (n > 0 && !small) { // (an empty shard of a sharded run launches nothing over its rows; the small-cloud kernel moves them itself)
         StageTimer t(ctx, ST_TRANSFORM);
-        if (pruned)
-            hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, d_src, src_perm, cur, n,
-                               (const IcpState *)st, 1, 0, d_tgt, (const int *)nullptr, m, frames, splits,
-                               blk_cnt, blk_list, work, work_cnt /* pass 0 reads counter 0 */);
-        else
-            hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, d_src,
-                               cur, n, st, 1, 0, src_perm);
+        hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, d_src, cur, n, st, 1, 0, src_perm);
+        if (bounded_loop) // the first pass's incumbents and bounds (and, culled engine, its group lists: set 0)
+            hipLaunchKernelGGL(k_nn_prebound1, dim3((n + 255) / 256), dim3(256), 0, s, (const double *)cur, n, (const double *)ctx->tgt_sorted.p,
+                               (const unsigned *)ctx->sort_keys.p + (size_t)m /* the sorted keys */,
+                               (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m, m, ctx->nn_ms, (const NnFrame *)ctx->nn_misc.p, idx, rb,
+                               frames, splits, pruned ? group_lists(ctx, 0) : GroupLists{nullptr, nullptr, 0});
     }
 
     unsigned long long *small_clocks = nullptr;
@@ -1252,11 +1290,11 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
             HIP_TRY(ctx, hipGetLastError());
             return ICPMI_OK;
         }
-        const bool fuse_step = sharded && !pruned && n > 0 && !final_pass;
-        const bool fuse_finish = !sharded && !pruned && n > 0 && !final_pass && fuse_finish_enabled();
+        const bool fuse_step = sharded && n > 0 && !final_pass;
+        const bool fuse_finish = !sharded && n > 0 && !final_pass && fuse_finish_enabled();
         if (n > 0 && fused) {
             if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, st, d_tgt, nrm, partials,
-                                     pruned ? pass_no : -1, bounded_loop && pass_no > 0 /* matches of the previous pass in idx, bounds in place */))) return r2;
+                                     pruned ? pass_no : -1, bounded_loop /* incumbents in idx, bounds in place: from k_nn_prebound1 or the kernel that moved the rows */))) return r2;
             ++pass_no;
         } else if (n > 0) {
             if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, st))) return r2;
@@ -1270,12 +1308,20 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
             if (sharded) {
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
                                    st);
-                if ((r2 = exchange_allreduce(ctx, st->sums, kNumExchanged))) return r2;
+                {
+                    StageTimer tx(ctx, ST_EXCHANGE); // the per-pass all-reduce alone (30 doubles; RCCL on the library's stream)
+                    if ((r2 = exchange_allreduce(ctx, st->sums, kNumExchanged))) return r2;
+                }
                 if (fuse_step) { // step + pose update of this rank's rows in one launch, into the other state buffer
                     IcpState *other = st == ctx->d_state ? ctx->d_state + 1 : ctx->d_state;
-                    hipLaunchKernelGGL(k_step_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
-                                       (const double *)cur, cur, n, (const IcpState *)st, other, hist, progress, ticket,
-                                       ctx->n_ranks, rb);
+                    if (pruned) // (+ the group lists of the coming pass: set pass_no & 1)
+                        hipLaunchKernelGGL(k_step_transform_cull, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
+                                           (const double *)cur, cur, n, (const IcpState *)st, other, hist, progress, ticket,
+                                           ctx->n_ranks, rb, frames, splits, group_lists(ctx, pass_no & 1));
+                    else
+                        hipLaunchKernelGGL(k_step_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
+                                           (const double *)cur, cur, n, (const IcpState *)st, other, hist, progress, ticket,
+                                           ctx->n_ranks, rb);
                     st = other;
                 } else {
                     hipLaunchKernelGGL(k_step, dim3(1), dim3(64), 0, s, st, hist, final_pass, progress, ticket,
@@ -1283,9 +1329,14 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                 }
             } else if (fuse_finish) { // final sum + step + pose update of the rows in one launch
                 IcpState *other = st == ctx->d_state ? ctx->d_state + 1 : ctx->d_state;
-                hipLaunchKernelGGL(k_finish_step_transform, dim3(finish_transform_blocks(n)), dim3(kFinishThreads), 0, s,
-                                   (const double *)partials, rblocks, n, (const double *)cur, cur, n,
-                                   (const IcpState *)st, other, hist, progress, ticket, rb);
+                if (pruned) // (+ the group lists of the coming pass: set pass_no & 1)
+                    hipLaunchKernelGGL(k_finish_step_transform_cull, dim3(finish_transform_blocks(n)), dim3(kFinishThreads), 0, s,
+                                       (const double *)partials, rblocks, n, (const double *)cur, cur, n, (const IcpState *)st, other,
+                                       hist, progress, ticket, rb, frames, splits, group_lists(ctx, pass_no & 1));
+                else
+                    hipLaunchKernelGGL(k_finish_step_transform, dim3(finish_transform_blocks(n)), dim3(kFinishThreads), 0, s,
+                                       (const double *)partials, rblocks, n, (const double *)cur, cur, n,
+                                       (const IcpState *)st, other, hist, progress, ticket, rb);
                 st = other;
             } else {
                 hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
@@ -1295,11 +1346,9 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         if (!final_pass && n > 0 && !fuse_step && !fuse_finish) {
             Range range("icpmi:transform");
             StageTimer t(ctx, ST_TRANSFORM);
-            if (pruned) // + each block's box and its exact distance bound to this iteration's neighbours
-                hipLaunchKernelGGL(k_transform_bounds, dim3(qblocks), dim3(kCoarseQueries), 0, s, (const double *)cur,
-                                   (const unsigned *)nullptr, cur, n, (const IcpState *)st, 0, 1, d_tgt,
-                                   (const int *)idx, m, frames, splits, blk_cnt, blk_list, work,
-                                   work_cnt + (pass_no & 1) /* the next pass's counter */, rb);
+            if (pruned) // (ICPMI_FUSE_FINISH=0 only: + the rows' bounds and the group lists of the coming pass, set pass_no & 1)
+                hipLaunchKernelGGL(k_transform_cull, dim3((n + 255) / 256), dim3(256), 0, s, (const double *)cur, (const unsigned *)nullptr,
+                                   cur, n, (const IcpState *)st, 0, 1, rb, frames, splits, group_lists(ctx, pass_no & 1));
             else
                 hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s,
                                    cur, cur, n, st, 0, 1, (const unsigned *)nullptr, rb);
@@ -1371,6 +1420,9 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     if (counters_back) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cnt, (char *)ctx->nn_misc.p + 128, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipMemsetAsync((char *)ctx->nn_misc.p + 128, 0, 3 * sizeof(unsigned long long), s));
+        ctx->h_cnt[3] = ctx->h_cnt[4] = 0;
+        if (pruned) // (row group, split) pairs run / of all passes: cleared with the counters at the head of the next call
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cnt + 3, group_stats(ctx), 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     }
     if (before_wait && ctx->opt.profile == 0) {
         // the results are waited for through an event; what before_wait queues behind it keeps the device busy
@@ -1394,6 +1446,10 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         ctx->prof.nn_recheck_queries += (int64_t)ctx->h_cnt[0];
         ctx->prof.nn_fallback_queries += (int64_t)ctx->h_cnt[1];
         ctx->prof.nn_pruned_blocks += (int64_t)ctx->h_cnt[2];
+        ctx->prof.nn_group_pairs_run += (int64_t)ctx->h_cnt[3];
+        ctx->prof.nn_group_pairs += (int64_t)ctx->h_cnt[4];
+        // (the older pair of fields, in 512-row units like the all-pairs engine's)
+        ctx->prof.nn_pruned_blocks += (int64_t)(ctx->h_cnt[4] - ctx->h_cnt[3]) / (kCoarseQueries / kGroupRows);
     }
     if (ctx->ev_used > 4096) harvest_profile(ctx); // (otherwise when the profile is asked for)
     if (hs->error)
@@ -1651,7 +1707,7 @@ int icpmi_create(const icpmi_options *opt, icpmi_ctx **out)
     if (hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
     if (hipHostMalloc((void **)&ctx->h_flags, sizeof(int32_t) * kFlagRing, hipHostMallocMapped) != hipSuccess) return bail("hipHostMalloc");
     if (hipHostMalloc((void **)&ctx->h_grid, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
-    if (hipHostMalloc((void **)&ctx->h_cnt, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
+    if (hipHostMalloc((void **)&ctx->h_cnt, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return bail("hipHostMalloc");
     memset(ctx->h_flags, 0, sizeof(int32_t) * kFlagRing);
     if (hipHostGetDevicePointer((void **)&ctx->d_flags, ctx->h_flags, 0) != hipSuccess) return bail("hipHostGetDevicePointer");
     *out = ctx;
@@ -1711,7 +1767,7 @@ void icpmi_destroy(icpmi_ctx *ctx)
     ctx->helpers.clear();
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
     for (DevBuf *b : {&ctx->cur, &ctx->nrm, &ctx->idx, &ctx->part_d2, &ctx->part_idx, &ctx->partials,
-                      &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out, &ctx->src_sort, &ctx->blk_lists, &ctx->work,
+                      &ctx->history, &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->d2out, &ctx->src_sort, &ctx->grp_cnt, &ctx->grp_items,
                       &ctx->bpack, &ctx->coarse, &ctx->bbox_part, &ctx->nn_misc, &ctx->knn_idx, &ctx->slotmin, &ctx->nn_lists, &ctx->nrm_sorted,
                       &ctx->fb_list, &ctx->sort_keys, &ctx->sort_tmp, &ctx->tgt_sorted, &ctx->frames, &ctx->vox_keys,
                       &ctx->vox_vals, &ctx->vox_out, &ctx->stream_prev, &ctx->stream_cur, &ctx->f32_stage, &ctx->grid_set,
@@ -2405,7 +2461,16 @@ int stream_register(icpmi_ctx *ctx, int64_t n_cur, int64_t min_points, const icp
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ctx->t_gpu_span += ms;
         }
-        if (rc) return rc;
+        if (rc) {
+            //  after_first may have queued the preparation of stream_cur on the helper: the buffers are not
+            // swapped on this path, so the NEXT push filters into stream_cur again -- not under the helper's reads
+            if (ctx->helper_busy) {
+                (void)hipEventSynchronize(ctx->prep_done);
+                ctx->helper_busy = false;
+                if (helper) helper->prep_valid = false;
+            }
+            return rc;
+        }
     }
     if (!queued_next && helper) (void)prepare_next(ctx); // (a failure only means the next push prepares its target itself)
     std::swap(ctx->stream_prev, ctx->stream_cur);         // prev_points_ = curr (slam_node.cpp:128,152), no copy
@@ -2877,6 +2942,52 @@ int icpmi_comm_init_callbacks(icpmi_ctx *ctx, int32_t n_ranks, int32_t rank,
     ctx->cb_user = user;
     ctx->n_ranks = n_ranks;
     ctx->rank = rank;
+    return ICPMI_OK;
+}
+
+// Who is in the communicator, asked of the communicator itself: its size and this rank from RCCL (ncclCommCount,
+// ncclCommUserRank, ncclCommCuDevice), and every rank's device ordinal and PCI bus id gathered through the library's own
+// all-gather -- the exchange the sharded normals use.  A collective: every rank must call it.
+int icpmi_comm_info(icpmi_ctx *ctx, icpmi_comm_info_t *out)
+{
+    int rc;
+    if ((rc = check_common(ctx))) return rc;
+    if (!out) return fail(ctx, ICPMI_ERR_NULL, "null argument");
+    memset(out, 0, sizeof(*out));
+    out->kind = ctx->comm ? 1 : (ctx->cb_allreduce ? 2 : 0);
+    out->n_ranks = ctx->n_ranks;
+    out->rank = ctx->rank;
+    int device = ctx->opt.device;
+    if (ctx->comm) {
+        int v = 0;
+        RCCL_TRY(ctx, ctx->rccl.CommCount(ctx->comm, &v));
+        out->n_ranks = v;
+        RCCL_TRY(ctx, ctx->rccl.CommUserRank(ctx->comm, &v));
+        out->rank = v;
+        RCCL_TRY(ctx, ctx->rccl.CommCuDevice(ctx->comm, &device));
+    }
+    const int nr = out->n_ranks;
+    if (nr > ICPMI_MAX_RANKS_INFO) return fail(ctx, ICPMI_ERR_ARG, "more than %d ranks", ICPMI_MAX_RANKS_INFO);
+    // one record of four doubles per rank: {device ordinal, 16 characters of PCI bus id, 0}
+    constexpr size_t per = 4;
+    double rec[per] = {0.0, 0.0, 0.0, 0.0};
+    char bus[32] = {0};
+    HIP_TRY(ctx, hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device));
+    rec[0] = (double)device;
+    memcpy(&rec[1], bus, 16);
+    if ((rc = reserve(ctx, ctx->stage_c, sizeof(double) * per * (size_t)nr))) return rc;
+    double *d = (double *)ctx->stage_c.p;
+    HIP_TRY(ctx, hipMemsetAsync(d, 0, sizeof(double) * per * (size_t)nr, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d + per * (size_t)out->rank, rec, sizeof(rec), hipMemcpyHostToDevice, ctx->stream));
+    if (out->kind != 0 && (rc = exchange_allgather(ctx, d, per))) return rc;
+    std::vector<double> host(per * (size_t)nr);
+    HIP_TRY(ctx, hipMemcpyAsync(host.data(), d, sizeof(double) * host.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < nr; ++r) {
+        out->device[r] = (int32_t)host[per * r];
+        memcpy(out->pci_bus_id[r], &host[per * r + 1], 16);
+        out->pci_bus_id[r][15] = '\0';
+    }
     return ICPMI_OK;
 }
 

@@ -1,0 +1,435 @@
+// nn_culled.h -- the culled correspondence search (ICPMI_SEARCH_MFMA_PRUNED, what AUTO runs on large targets), round 4:
+// the cull at WAVE granularity.
+//
+// The reference's search is a culling search: KDTree::nearest_recursive (kdtree.hpp:112-142) leaves a subtree as soon as
+// the splitting plane is farther away than the best distance so far.  Here the same rule is applied to whole groups of
+// rows against whole splits of the target, before any pair is evaluated:
+//   * the rows of the moved source are kept in Morton order (one sort per call), so 64 consecutive rows -- what ONE
+//     wave of the coarse pass works on -- are a compact blob: their bounding box is a few nearest-neighbour distances wide;
+//   * every row comes with a bound ub(row) on its nearest-neighbour distance before the pass starts: the exact distance
+//     to the target it was matched with one pass ago (RowBounds, kernels.h) or, in a call's first pass, to the nearest
+//     of the sorted targets around the row's own place in the target's Morton order (k_nn_prebound1);
+//   * a split s of 2048 sorted targets can hold a target within ub(row) of a row of group g only if
+//     gap^2(box(g), box(s)) <= max over the group's rows of ub: every other (group, split) pair is culled -- strictly
+//     greater, with a margin for the test's own roundings, so not even a target at EQUAL distance is lost and the
+//     lowest-index tie rule survives;
+//   * the surviving pairs are appended to one list per SPLIT (wave_cull), and k_nn_coarse_groups runs the MFMA unit of
+//     nn_mfma.h on them: a workgroup takes eight groups of ONE split's list -- any eight, they need not be neighbours --
+//     stages the split's operands through LDS once and gives each wave one group.  The epilogue is MODE 2's: the slots
+//     under the row's per-split threshold tau_s(ub(row)) are listed per row, and k_nn_resolve_bounded (nn_bounded.h) scans
+//     the listed slots exactly, the bound's target as the incumbent.
+// Round 3 culled (512-row block, split) pairs: 84 % of them at C3, and a surviving pair cost all eight waves of a unit
+// their 128 MFMAs although most of the eight had nothing within reach.  At 64 rows the box is half as wide per axis.
+// Exactness is the argument of nn_bounded.h unchanged: a target within the row's final distance <= ub(row) lies in a
+// split whose box is within sqrt(ub(row)) <= sqrt(max ub) of the row, hence of the group's box; that pair is evaluated,
+// the target's slot is listed for the row and scanned.  Rows whose list does not fit take the resolve's exhaustive
+// search behind the split and slot boxes, which needs no list at all.
+#pragma once
+#include "nn_mfma.h"
+
+namespace icpmi {
+
+constexpr int kGroupRows = 64;          // rows per group: one wave's two 32-row MFMA tiles
+constexpr int kCullMaxSplits = 4096;    // splits whose chunk prefix fits the coarse kernel's LDS (8.4M targets); beyond: all pairs
+static_assert(kGroupRows == kTile * kCoarseQT, "a group is what one wave of the coarse unit takes");
+
+// One list of row groups per target split (the pairs that survived the box test), for the coming coarse pass.
+struct GroupLists {
+    unsigned *cnt;    // [nsplits] groups appended so far (nullptr: no culling wanted)
+    unsigned *items;  // [nsplits][cap]
+    int cap;          // groups a list can hold = groups of the pass (a group enters a split's list at most once)
+};
+
+// The box test, by one whole wave for group g: (lo, hi, ub) are the lanes' own rows (a lane without a row: lo = +big,
+// hi = -big, ub = 0); reduced here over the wave.  `ub` may be +Inf (a row without any bound) or NaN-free by the
+// caller's care; an infinite bound is replaced by the one that needs no match at all: every split holds a target, and
+// that target is no farther from any row of the group than the largest distance between the two boxes.
+__device__ __forceinline__ void wave_cull(const int g, double (&lo)[3], double (&hi)[3], double ub,
+                                          const SplitFrame *__restrict__ frames, const int nsplits, const GroupLists &gl,
+                                          const int lane)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double l2 = __shfl_xor(lo[a], off, 64), h2 = __shfl_xor(hi[a], off, 64);
+            lo[a] = l2 < lo[a] ? l2 : lo[a];
+            hi[a] = h2 > hi[a] ? h2 : hi[a];
+        }
+        const double u2 = __shfl_xor(ub, off, 64);
+        ub = u2 > ub ? u2 : ub;
+    }
+    if (!(lo[0] <= hi[0])) return; // no finite row in the group: nothing to search for
+    if (!(ub < 1.0e300)) {
+        double far2 = __builtin_inf();
+        for (int s = lane; s < nsplits; s += 64) {
+            double f2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double f1 = hi[a] - frames[s].lo[a], f3 = frames[s].hi[a] - lo[a];
+                const double f = f1 > f3 ? f1 : f3;
+                f2 += f * f;
+            }
+            far2 = f2 < far2 ? f2 : far2; // (an empty split's inverted box gives a huge value or NaN: never the minimum)
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(far2, off, 64);
+            far2 = o < far2 ? o : far2;
+        }
+        ub = far2 * (1.0 + 1e-12); // (+Inf when no split has a finite target: everything is kept, nothing is found)
+    }
+    for (int s0 = 0; s0 < nsplits; s0 += 64) {
+        const int s = s0 + lane;
+        if (s < nsplits) {
+            double g2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double g1 = lo[a] - frames[s].hi[a], g3 = frames[s].lo[a] - hi[a];
+                const double gg = g1 > g3 ? g1 : g3;
+                g2 += gg > 0.0 ? gg * gg : 0.0;
+            }
+            if (!(g2 * (1.0 - 1e-12) > ub * (1.0 + 1e-12))) {
+                const unsigned pos = atomicAdd(gl.cnt + s, 1u);
+                gl.items[(size_t)s * gl.cap + pos] = (unsigned)g;
+            }
+        }
+    }
+}
+
+// What a kernel that moves rows leaves for the bounded pass that follows (RowBatch::finish's images, kernels.h), for one
+// row per lane; returns the row's contribution to its group's box and bound.
+__device__ __forceinline__ void row_bound_store(const RowBounds &rb, const int i, const bool valid, const double px, const double py,
+                                                const double pz, const bool have, const double tx, const double ty, const double tz,
+                                                double (&lo)[3], double (&hi)[3], double &ubg)
+{
+    lo[0] = lo[1] = lo[2] = 1.7e308;
+    hi[0] = hi[1] = hi[2] = -1.7e308;
+    ubg = 0.0;
+    if (!valid) return;
+    double ub = __builtin_inf();
+    float ubf = __builtin_nanf(""), sqf = 0.f;
+    const bool fin = __builtin_isfinite(px) && __builtin_isfinite(py) && __builtin_isfinite(pz);
+    if (fin) {
+        if (have) ub = sqdist(tx, ty, tz, px, py, pz);
+        ubf = (float)ub;
+        ubf = (double)ubf < ub ? __uint_as_float(__float_as_uint(ubf) + 1u) : ubf; // (ub >= 0; Inf stays Inf)
+        sqf = __builtin_amdgcn_sqrtf(ubf);
+        sqf = sqf < 3.0e38f ? __uint_as_float(__float_as_uint(sqf) + 2u) : sqf;   // (1 ulp of v_sqrt_f32 and one more)
+        lo[0] = hi[0] = px, lo[1] = hi[1] = py, lo[2] = hi[2] = pz;
+        ubg = ub == ub ? ub : __builtin_inf(); // (a NaN distance -- a non-finite target behind the match: cannot happen, kept safe)
+    }
+    rb.ub[i] = ub;
+    rb.ubf[i] = ubf;
+    rb.sqf[i] = sqf;
+    rb.cnt[i] = 0;
+}
+
+// ---- a call's FIRST pass: the bound from the row's place in the target's Morton order ---------------------------------
+// One row per lane.  The row's Morton key in the target's frame (k_morton_keys' arithmetic) is looked up in the sorted
+// keys; the kPreWindow sorted positions around that place are neighbours of the row in space wherever the curve is
+// continuous, and the nearest of them, exactly measured, is a real target: its distance bounds the row's nearest-
+// neighbour distance like a previous match does, and it is written to idx[] AS the previous match.  Rows of a wave are
+// neighbours too (the source is in Morton order), so their windows overlap and the loads mostly hit the same lines.
+// With group lists the wave then culls the splits for its 64 rows (pruned engine).
+constexpr int kPreWindow = 128;
+__global__ __launch_bounds__(256) void k_nn_prebound1(const double *__restrict__ cur, int n, const double *__restrict__ sorted,
+                                                      const unsigned *__restrict__ keys_sorted, const unsigned *__restrict__ perm,
+                                                      int m, int ms, const NnFrame *__restrict__ frame, int *__restrict__ idx,
+                                                      const RowBounds rb, const SplitFrame *__restrict__ frames, int nsplits,
+                                                      const GroupLists gl)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    const int ic = valid ? i : n - 1;
+    const double px = cur[3 * ic], py = cur[3 * ic + 1], pz = cur[3 * ic + 2];
+    unsigned key;
+    {
+        double ext = 0.0;
+        for (int a = 0; a < 3; ++a) ext = frame->hi[a] - frame->lo[a] > ext ? frame->hi[a] - frame->lo[a] : ext;
+        unsigned q[3];
+        for (int a = 0; a < 3; ++a) {
+            double f = ext > 0.0 ? ((a == 0 ? px : a == 1 ? py : pz) - frame->lo[a]) / ext : 0.0;
+            f = !(f >= 0.0) ? 0.0 : (f > 1.0 ? 1.0 : f);
+            const int qi = (int)(f * 1023.0);
+            q[a] = (unsigned)(qi < 0 ? 0 : (qi > 1023 ? 1023 : qi));
+        }
+        key = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    }
+    int lo_p = 0, hi_p = m;
+    while (lo_p < hi_p) {
+        const int mid = (lo_p + hi_p) >> 1;
+        if (keys_sorted[mid] < key) lo_p = mid + 1;
+        else hi_p = mid;
+    }
+    int w0 = lo_p - kPreWindow / 2;
+    w0 = w0 + kPreWindow > m ? m - kPreWindow : w0;
+    w0 = w0 < 0 ? 0 : w0;
+    const int w1 = w0 + kPreWindow < m ? w0 + kPreWindow : m;
+    double bd = 1.7976931348623157e308;
+    int bj = -1;
+#pragma unroll 8
+    for (int j = w0; j < w1; ++j) {
+        const double d = sqdist(ICPMI_SX(sorted, ms, j), ICPMI_SY(sorted, ms, j), ICPMI_SZ(sorted, ms, j), px, py, pz);
+        if (d < bd) { // (a NaN or infinite distance -- a non-finite target or row -- never enters)
+            bd = d;
+            bj = j;
+        }
+    }
+    const bool have = bj >= 0;
+    const int jo = have ? (int)perm[bj] : -1;
+    if (valid) idx[i] = jo;
+    double lo[3], hi[3], ubg;
+    // (the bound is restated from the target's coordinates exactly as RowBatch::finish forms it from the caller's array:
+    // the sorted copy holds the same doubles)
+    const int bjc = have ? bj : 0;
+    row_bound_store(rb, i, valid, px, py, pz, have, ICPMI_SX(sorted, ms, bjc), ICPMI_SY(sorted, ms, bjc), ICPMI_SZ(sorted, ms, bjc), lo, hi,
+                    ubg);
+    if (gl.cnt) wave_cull(i / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
+}
+
+// ---- the pose update of the rows with the next pass's bounds and group lists -------------------------------------------
+// k_transform's work (icp.hpp:174-176, 225-226) for one row per lane, 64 consecutive rows per wave = one group; the rows'
+// bounds like RowBatch::finish, then the box test of the group.  Used where the step is a kernel of its own (sharded runs:
+// the all-reduce sits between the sums and the step).
+__global__ __launch_bounds__(256) void k_transform_cull(const double *in, const unsigned *__restrict__ perm, double *out, int n,
+                                                        const IcpState *__restrict__ st, int which, int honour_done,
+                                                        const RowBounds rb, const SplitFrame *__restrict__ frames, int nsplits,
+                                                        const GroupLists gl)
+{
+    if (honour_done && st->done) return;
+    const double *T = which ? st->total : st->delta;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    double p[3] = {0.0, 0.0, 0.0}, t[3] = {0.0, 0.0, 0.0};
+    bool have = false;
+    if (valid) {
+        const size_t si = perm ? perm[i] : (unsigned)i;
+        const double x = in[3 * si], y = in[3 * si + 1], z = in[3 * si + 2];
+        const int j = rb.tgt && rb.idx ? rb.idx[i] : -1;
+        have = (unsigned)j < (unsigned)rb.m;
+        if (have) t[0] = rb.tgt[3 * (size_t)j], t[1] = rb.tgt[3 * (size_t)j + 1], t[2] = rb.tgt[3 * (size_t)j + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) p[r] = ((x * T[4 * r] + y * T[4 * r + 1]) + z * T[4 * r + 2]) + T[4 * r + 3];
+        out[3 * i] = p[0];
+        out[3 * i + 1] = p[1];
+        out[3 * i + 2] = p[2];
+    }
+    if (!rb.ub) return;
+    double lo[3], hi[3], ubg;
+    row_bound_store(rb, i, valid, p[0], p[1], p[2], have, t[0], t[1], t[2], lo, hi, ubg);
+    if (gl.cnt) wave_cull(i / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
+}
+
+// Single GPU: final sum + step + pose update of the rows (k_finish_step_transform, kernels.h) + the rows' bounds and the
+// group lists of the coming pass, in one launch.  Every workgroup sums all partial rows itself and repeats the step on
+// its own copy of the state; a wave takes whole groups (64 consecutive rows), a row per lane.
+__global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform_cull(
+    const double *__restrict__ partials, int nblocks, int n_local, const double *in, double *out, int n, const IcpState *sin,
+    IcpState *sout, double *history, int *progress, int ticket, const RowBounds rb, const SplitFrame *__restrict__ frames,
+    int nsplits, const GroupLists gl)
+{
+    __shared__ IcpState ls, sums; // `sums`: only its sums[] are used
+    const int lane = threadIdx.x & 63;
+    const int i0 = blockIdx.x * kFinishThreads + threadIdx.x, stride = gridDim.x * kFinishThreads;
+    // everything that does not depend on the state is requested first: this thread's first row, its previous match and
+    // that target; the partial rows (k_finish_step_transform's order of business)
+    double x = 0.0, y = 0.0, z = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
+    bool have = false;
+    auto load_row = [&](const int i) {
+        x = y = z = tx = ty = tz = 0.0;
+        have = false;
+        if (i < n) {
+            x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+            const int j = rb.idx[i];
+            have = (unsigned)j < (unsigned)rb.m;
+            if (have) tx = rb.tgt[3 * (size_t)j], ty = rb.tgt[3 * (size_t)j + 1], tz = rb.tgt[3 * (size_t)j + 2];
+        }
+    };
+    load_row(i0);
+    state_copy(&ls, sin);
+    finish_sums(partials, nblocks, n_local, &sums);
+    __syncthreads();
+    if (!ls.done && threadIdx.x < kNumSums) ls.sums[threadIdx.x] = sums.sums[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        step_update(&ls, blockIdx.x == 0 ? history : nullptr, 0);
+        if (blockIdx.x == 0) publish_progress(progress, ticket, ls.done);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) state_copy(sout, &ls);
+    if (ls.done) return; // the loop ended before or in this step: the source stays where it is (icp.hpp:210-217)
+    const double *T = ls.delta;
+    const double r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3];
+    const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
+    const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
+    // (wave-uniform trip count: a wave's 64 rows start at a multiple of 64, so the wave's first lane decides)
+    for (int base = i0; base - lane < n; base += stride) {
+        if (base != i0) load_row(base);
+        const bool valid = base < n;
+        const double px = ((x * r00 + y * r01) + z * r02) + t0;
+        const double py = ((x * r10 + y * r11) + z * r12) + t1;
+        const double pz = ((x * r20 + y * r21) + z * r22) + t2;
+        if (valid) {
+            out[3 * base] = px;
+            out[3 * base + 1] = py;
+            out[3 * base + 2] = pz;
+        }
+        double lo[3], hi[3], ubg;
+        row_bound_store(rb, base, valid, px, py, pz, have, tx, ty, tz, lo, hi, ubg);
+        wave_cull((base - lane) / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
+    }
+}
+
+// Sharded runs: k_step_transform (kernels.h) with the group lists -- the step from the all-reduced sums repeated by every
+// workgroup, the pose update of this rank's rows, their bounds, the box test of their groups.
+__global__ __launch_bounds__(256) void k_step_transform_cull(const double *in, double *out, int n, const IcpState *sin, IcpState *sout,
+                                                             double *history, int *progress, int ticket, int n_ranks, const RowBounds rb,
+                                                             const SplitFrame *__restrict__ frames, int nsplits, const GroupLists gl)
+{
+    __shared__ IcpState ls;
+    const int lane = threadIdx.x & 63;
+    const int i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    double x = 0.0, y = 0.0, z = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
+    bool have = false;
+    auto load_row = [&](const int i) {
+        x = y = z = tx = ty = tz = 0.0;
+        have = false;
+        if (i < n) {
+            x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+            const int j = rb.idx[i];
+            have = (unsigned)j < (unsigned)rb.m;
+            if (have) tx = rb.tgt[3 * (size_t)j], ty = rb.tgt[3 * (size_t)j + 1], tz = rb.tgt[3 * (size_t)j + 2];
+        }
+    };
+    load_row(i0);
+    state_copy(&ls, sin);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ndone = ls.sums[kDoneSlot];
+        const bool all = ndone == (double)n_ranks, some = ndone > 0.0 && !all;
+        if (some) {
+            ls.error = 1;
+            ls.done = 1;
+        }
+        step_update(&ls, blockIdx.x == 0 ? history : nullptr, 0);
+        if (blockIdx.x == 0) publish_progress(progress, ticket, all || some);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) state_copy(sout, &ls);
+    if (ls.done) return;
+    const double *T = ls.delta;
+    const double r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3];
+    const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
+    const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
+    for (int base = i0; base - lane < n; base += stride) {
+        if (base != i0) load_row(base);
+        const bool valid = base < n;
+        const double px = ((x * r00 + y * r01) + z * r02) + t0;
+        const double py = ((x * r10 + y * r11) + z * r12) + t1;
+        const double pz = ((x * r20 + y * r21) + z * r22) + t2;
+        if (valid) {
+            out[3 * base] = px;
+            out[3 * base + 1] = py;
+            out[3 * base + 2] = pz;
+        }
+        double lo[3], hi[3], ubg;
+        row_bound_store(rb, base, valid, px, py, pz, have, tx, ty, tz, lo, hi, ubg);
+        wave_cull((base - lane) / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
+    }
+}
+
+// ---- normal estimation: the groups are runs of 64 sorted target rows, their bound the largest of the rows' own ----------
+// (k_knn_prebound's T: the k-th neighbour of every row lies within it).  One wave per group; rows = sorted positions
+// row0 .. row0 + nrows, groups and bounds numbered from the launch's first row (row0 a multiple of 64).
+__global__ __launch_bounds__(256) void k_knn_group_cull(const double *__restrict__ sorted, int m, int ms, int row0, int nrows,
+                                                        const double *__restrict__ t_row, const SplitFrame *__restrict__ frames,
+                                                        int nsplits, const GroupLists gl)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int local = g * kGroupRows + lane;
+    if (g * kGroupRows >= nrows) return;
+    const int j = row0 + local;
+    const bool valid = local < nrows && j < m;
+    double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308}, ub = 0.0;
+    if (valid) {
+        const double x = ICPMI_SX(sorted, ms, j), y = ICPMI_SY(sorted, ms, j), z = ICPMI_SZ(sorted, ms, j);
+        if (finite3(x, y, z)) { // (a non-finite row has no neighbours: its list stays empty and the exact kernel answers)
+            lo[0] = hi[0] = x, lo[1] = hi[1] = y, lo[2] = hi[2] = z;
+            const double t = t_row[local];
+            ub = t == t ? t : __builtin_inf();
+        }
+    }
+    wave_cull(g, lo, hi, ub, frames, nsplits, gl, lane);
+}
+
+// ---- the coarse pass over the group lists ------------------------------------------------------------------------------
+// One (row group, split) pair per wave, eight pairs of the SAME split per workgroup: the unit of nn_mfma.h (operands of the
+// split staged through LDS in two chunks, 128 MFMAs per wave, MODE 2 epilogue) with each wave's rows taken from the
+// split's list.  A fixed grid strides over the chunks of all lists: chunk c belongs to the split s with
+// pre[s] <= c < pre[s + 1], pre = the running sum of ceil(cnt[s] / 8) -- formed by every workgroup for itself (a few
+// dozen loads and one wave scan), so no kernel sits between the box test and this one.  `cnt_next`: the counters the NEXT
+// pass's lists will be appended to (by the kernel that moves the rows after this pass); nobody reads or writes them while
+// this kernel runs, so they are cleared here.
+template <bool QSOA, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nn_coarse_groups(
+    const double *__restrict__ qry, int n, size_t qstride, const uint4 *__restrict__ Bpack, const SplitFrame *__restrict__ frames,
+    int nsplits, const unsigned *__restrict__ items, int cap, const unsigned *__restrict__ cnt, unsigned *__restrict__ cnt_next,
+    unsigned long long *__restrict__ stats /* [0] += pairs run, [1] += pairs of the pass (may be null) */, unsigned long long pairs_total,
+    const IcpState *__restrict__ st, const KnnLists kl)
+{
+    if (st && st->done) return;
+    __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
+    __shared__ unsigned pre[kCullMaxSplits + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        unsigned run = 0, listed = 0;
+        for (int s0 = 0; s0 < nsplits; s0 += 64) {
+            const int s = s0 + lane;
+            const unsigned c = s < nsplits ? cnt[s] : 0u;
+            const unsigned ch = (c + WAVES - 1) / WAVES;
+            unsigned inc = ch, tot = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(inc, off, 64);
+                inc += lane >= off ? o : 0u;
+                tot += __shfl_xor(tot, off, 64);
+            }
+            if (s < nsplits) pre[s] = run + inc - ch;
+            run += __shfl(inc, 63, 64);
+            listed += tot;
+        }
+        if (lane == 0) {
+            pre[nsplits] = run;
+            if (blockIdx.x == 0 && stats) {
+                atomicAdd(stats, (unsigned long long)listed);
+                atomicAdd(stats + 1, pairs_total);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && cnt_next)
+        for (int s = threadIdx.x; s < nsplits; s += 64 * WAVES) cnt_next[s] = 0u;
+    __syncthreads();
+    const unsigned total = pre[nsplits];
+#pragma unroll 1
+    for (unsigned c = blockIdx.x; c < total; c += gridDim.x) {
+        int slo = 0, shi = nsplits; // pre[slo] <= c < pre[shi]
+        while (shi - slo > 1) {
+            const int mid = (slo + shi) >> 1;
+            if (pre[mid] <= c) slo = mid;
+            else shi = mid;
+        }
+        const int s = __builtin_amdgcn_readfirstlane(slo);
+        const unsigned item = (c - pre[s]) * WAVES + (unsigned)wave;
+        const bool active = item < cnt[s];
+        const int g = __builtin_amdgcn_readfirstlane(active ? (int)items[(size_t)s * cap + item] : 0);
+        coarse_unit_rows<2, kCoarseQT, WAVES, QSOA>(lds, g * kGroupRows, active, s, nsplits, qry, n, qstride, Bpack, frames, nullptr, nullptr,
+                                                    kl);
+        __syncthreads(); // the epilogue's LDS is the next chunk's operand buffer
+    }
+}
+
+} // namespace icpmi

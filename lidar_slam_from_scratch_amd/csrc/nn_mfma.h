@@ -53,15 +53,14 @@
 // Round 3: where a row comes WITH a bound on the distance it looks within, the coarse pass keeps no minima at all -- its
 // epilogue (MODE 2) lists the slots under the bound's per-split threshold and the resolve scans the listed slots:
 // knn_lists.h (normal estimation: the bound from the target's Morton order) and nn_bounded.h (the ICP loop from its second
-// pass on: the bound from each row's previous match).  The forms described above remain for a call's first pass, the
-// stand-alone searches and the pruned engine.
+// pass on: the bound from each row's previous match; round 4: the first pass too, the bound from the row's place in the target's
+// Morton order, nn_culled.h).  The forms described above remain for the stand-alone searches and as the A/B reference
+// (ICPMI_NN_BOUNDED=0).
 //
-// Engine 3 (ICPMI_SEARCH_MFMA_PRUNED, opt-in) runs the same coarse unit and the same resolve on
-// fewer (query block, split) units: k_transform_bounds / k_knn_block_bounds bound, per block of
-// 512 queries, the distance within which every query finds its answer, cull_block keeps the
-// splits whose bounding box is within that distance of the block's, k_nn_coarse_list walks the
-// surviving units and the resolves read each block's split list.  The cull is conservative
-// (strict inequality, margins for its own roundings), so the result is the same, ties included.
+// Engine 3 (ICPMI_SEARCH_MFMA_PRUNED; what AUTO takes on targets of more than 16 splits) runs the same coarse unit and
+// the bounded resolve on the (64-row group, split) pairs whose boxes are within the group's bound of each other:
+// nn_culled.h.  The cull is conservative (strict inequality, margins for its own roundings), so the result is the
+// same, ties included.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -126,14 +125,6 @@ struct SplitFrame {  // per split of 2048 sorted targets
     double rho;      // >= max |q - c| over the split (inflated)
     double lo[3], hi[3]; // exact bounding box of the split's targets
 };
-// Per block of kCoarseQueries consecutive queries (pruned engine): bounding box of the block
-// and an upper bound of every member's nearest-neighbour squared distance.
-struct BlockBounds {
-    double lo[3], hi[3];
-    double ub;       // max over the block of |query - its previous nearest target|^2 (inf: unknown)
-    double pad;
-};
-
 // ---- bounding box -----------------------------------------------------------------------------
 // A target with a non-finite coordinate is never anybody's nearest neighbour (kdtree.hpp:125: no
 // `dist_sq < best` holds for an infinite or NaN distance), so the search structures are built
@@ -629,18 +620,19 @@ __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const
 
 // One (query block, split) unit of the coarse pass: 512 queries against 2048 targets, the targets
 // staged through one 32 KiB LDS buffer in two chunks.
+// `q0`: the wave's first row; `active` (wave-uniform): a wave without rows of its own (the culled engine's last chunk
+// of a split's list, nn_culled.h) still stages operands and meets the barriers, and does nothing else.
 template <int MODE, int QT, int WAVES, bool QSOA = false>
-__device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int s, const int nsplits,
-                                            const double *__restrict__ qry, const int n, const size_t qstride,
-                                            const uint4 *__restrict__ Bpack,
-                                            const SplitFrame *__restrict__ frames,
-                                            float2 *__restrict__ coarse, float *__restrict__ slotmin,
-                                            const KnnLists kl = KnnLists{nullptr, nullptr, nullptr, nullptr, 0})
+__device__ __forceinline__ void coarse_unit_rows(uint4 *lds, const int q0, const bool active, const int s, const int nsplits,
+                                                 const double *__restrict__ qry, const int n, const size_t qstride,
+                                                 const uint4 *__restrict__ Bpack,
+                                                 const SplitFrame *__restrict__ frames,
+                                                 float2 *__restrict__ coarse, float *__restrict__ slotmin,
+                                                 const KnnLists kl = KnnLists{nullptr, nullptr, nullptr, nullptr, 0}, const int bx = 0)
 {
     constexpr int THREADS = 64 * WAVES;
     constexpr int CHUNK16 = kChunkTiles * 64;  // uint4 per staged chunk (32 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q0 = (bx * WAVES + wave) * (kTile * QT);
 #ifdef ICPMI_COARSE_CLOCKS /* diagnostic build only (scripts/coarse_clock.py): the clock the chip holds inside this
                               kernel = d(s_memtime) / d(s_memrealtime) x 100 MHz; the 1-NN pass gets a stamp buffer
                               through the otherwise unused `slotmin` argument */
@@ -653,12 +645,12 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
     const double c0 = frames[s].c[0], c1 = frames[s].c[1], c2 = frames[s].c[2];
 
     bf16x8 afrag[QT];
-    float pn[(QT + 1) / 2], p2[(QT + 1) / 2], thr[(QT + 1) / 2];
-    coarse_build_a<QT, QSOA>(lds + wave * (64 * 2), lane, q0, qry, n, qstride, c0, c1, c2, afrag, pn, p2);
+    float pn[(QT + 1) / 2] = {}, p2[(QT + 1) / 2] = {}, thr[(QT + 1) / 2];
+    if (active) coarse_build_a<QT, QSOA>(lds + wave * (64 * 2), lane, q0, qry, n, qstride, c0, c1, c2, afrag, pn, p2);
 #pragma unroll
     for (int gq = 0; gq < (QT + 1) / 2; ++gq) {
         thr[gq] = 0.f;
-        if (MODE == 2) {
+        if (MODE == 2 && active) {
             // tau_s(d) of nn_mfma.h's header for d = the row's bound, in fp32 with every input rounded up: a >= |p - c_s| + rho_s
             // from the represented point (within 2^-16 of the true one) and the split's radius, 1e-4 over; the last factor
             // covers this evaluation's own roundings and tau_from_a's 5e-6.  A NaN bound (a row with a non-finite coordinate)
@@ -694,12 +686,13 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
         for (int e = 0; e < CHUNK16 / THREADS; ++e)
             lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
         __syncthreads();
-        coarse_tiles<QT, kChunkTiles>(lds, lane, afrag, m, zero);
+        if (active) coarse_tiles<QT, kChunkTiles>(lds, lane, afrag, m, zero);
     }
 
     __syncthreads(); // every wave is done with the B operands
-    coarse_epilogue<MODE, QT>(reinterpret_cast<float *>(lds) + wave * (32 * 36), lane, q0, s, nsplits, n, m, pn, coarse,
-                              slotmin, kl, thr);
+    if (active)
+        coarse_epilogue<MODE, QT>(reinterpret_cast<float *>(lds) + wave * (32 * 36), lane, q0, s, nsplits, n, m, pn, coarse,
+                                  slotmin, kl, thr);
 #ifdef ICPMI_COARSE_CLOCKS
     if (MODE == 0 && slotmin && threadIdx.x == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(slotmin) + 4 * ((size_t)bx * nsplits + s);
@@ -709,6 +702,19 @@ __device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int 
         o[3] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
+}
+
+// One (query block, split) unit: wave w of block bx takes rows (bx * WAVES + w) * 32 QT ...
+template <int MODE, int QT, int WAVES, bool QSOA = false>
+__device__ __forceinline__ void coarse_unit(uint4 *lds, const int bx, const int s, const int nsplits,
+                                            const double *__restrict__ qry, const int n, const size_t qstride,
+                                            const uint4 *__restrict__ Bpack,
+                                            const SplitFrame *__restrict__ frames,
+                                            float2 *__restrict__ coarse, float *__restrict__ slotmin,
+                                            const KnnLists kl = KnnLists{nullptr, nullptr, nullptr, nullptr, 0})
+{
+    coarse_unit_rows<MODE, QT, WAVES, QSOA>(lds, (bx * WAVES + (int)(threadIdx.x >> 6)) * (kTile * QT), true, s, nsplits, qry, n, qstride,
+                                            Bpack, frames, coarse, slotmin, kl, bx);
 }
 
 template <int WAVES>
@@ -757,276 +763,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_coarse_bounded(
 // staging, A rows and epilogue transposes in wave-private LDS.  315 us against 311 us on C3: the
 // per-unit form's staging phases and barriers are not what its time goes to.)
 
-// Pruned engine: the units that survived the box test (k_transform_bounds) are listed in
-// `work` (unit = block * nsplits + split, any order); a fixed grid strides over the list, so
-// no workgroup is launched for a culled unit.  `count_next` is the counter the NEXT list
-// will be appended to (by the k_transform_bounds that follows this pass): nobody reads or
-// writes it while this kernel runs, so it is cleared here.
-template <int MODE, bool QSOA, int QT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nn_coarse_list(
-    const double *__restrict__ qry, int n, size_t qstride, const uint4 *__restrict__ Bpack,
-    const SplitFrame *__restrict__ frames, float2 *__restrict__ coarse /*[split][n]*/,
-    float *__restrict__ slotmin /*[n][nsplits*32], MODE 1*/, int nsplits,
-    const unsigned *__restrict__ work, const unsigned *__restrict__ count, unsigned *__restrict__ count_next,
-    unsigned total_units, unsigned long long *__restrict__ culled_count, const IcpState *__restrict__ st,
-    const KnnLists kl = KnnLists{nullptr, nullptr, nullptr, nullptr, 0} /* MODE 2: the rows' lists (nn_bounded.h) */)
-{
-    if (st && st->done) return;
-    __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
-    const unsigned cnt = *count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (count_next) *count_next = 0u;
-        if (culled_count) atomicAdd(culled_count, (unsigned long long)(total_units - cnt));
-    }
-#pragma unroll 1
-    for (unsigned w = blockIdx.x; w < cnt; w += gridDim.x) {
-        const unsigned unit = (unsigned)__builtin_amdgcn_readfirstlane((int)work[w]); // uniform: keep it scalar
-        const int bx = (int)(unit / (unsigned)nsplits), s = (int)(unit % (unsigned)nsplits);
-        coarse_unit<MODE, QT, WAVES, QSOA>(lds, bx, s, nsplits, qry, n, qstride, Bpack, frames, coarse, slotmin, kl);
-        __syncthreads(); // the epilogue's LDS is the next unit's operand buffer
-    }
-}
-
-// The box test of the pruned engine, run by one wave for query block `b` with bounding box
-// [lo, hi] and `ub` >= the squared distance within which every query of the block is known to
-// find what it looks for (its nearest target; its k-th nearest for normals).  No target of
-// split s is closer to any query of the block than the gap between the two boxes: if
-// gap^2 > ub, strictly (with a margin for the roundings of the test itself), split s holds
-// nothing that can enter the answer, not even at equal distance.  Survivors go, ascending, to
-// the block's list (read by the resolve) and, in any order, to the pass's work list (read by
-// k_nn_coarse_list).
-__device__ __forceinline__ void cull_block(const int b, const double *lo, const double *hi, const double ub,
-                                           const SplitFrame *__restrict__ frames, const int nsplits,
-                                           int *__restrict__ blk_cnt, int *__restrict__ blk_list,
-                                           unsigned *__restrict__ work, unsigned *__restrict__ work_count,
-                                           const int lane)
-{
-    int base = 0;
-    for (int s0 = 0; s0 < nsplits; s0 += 64) {
-        const int s = s0 + lane;
-        bool act = false;
-        if (s < nsplits) {
-            double g2 = 0.0;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double g1 = lo[a] - frames[s].hi[a], g3 = frames[s].lo[a] - hi[a];
-                const double g = g1 > g3 ? g1 : g3;
-                g2 += g > 0.0 ? g * g : 0.0;
-            }
-            act = !(g2 * (1.0 - 1e-12) > ub * (1.0 + 1e-12));
-        }
-        const unsigned long long mask = __ballot(act);
-        const int cnt = __popcll(mask);
-        unsigned gbase = 0;
-        if (lane == 0 && cnt) gbase = atomicAdd(work_count, (unsigned)cnt);
-        gbase = __shfl(gbase, 0, 64);
-        if (act) {
-            const int r = __popcll(mask & ((1ull << lane) - 1ull));
-            blk_list[(size_t)b * nsplits + base + r] = s;
-            work[gbase + r] = (unsigned)b * (unsigned)nsplits + (unsigned)s;
-        }
-        base += cnt;
-    }
-    if (lane == 0) blk_cnt[b] = base;
-}
-
-// ---- pose update + block bounds (pruned engine) ---------------------------------------------------
-// out[i] = T * in[src(i)] like k_transform (icp.hpp:174-176,225-226), src(i) = perm[i] when a
-// permutation is given (Morton order of the source, applied once with the initial transform);
-// the same pass measures, exactly, the distance from the moved point to its previous nearest
-// target and reduces the block's bounding box and the maximum of those distances.
-__global__ __launch_bounds__(kCoarseQueries) void k_transform_bounds(
-    const double *in, const unsigned *__restrict__ perm, double *out, int n,
-    const IcpState *__restrict__ st, int which, int honour_done, const double *__restrict__ tgt,
-    const int *__restrict__ prev_idx, int m, const SplitFrame *__restrict__ frames, int nsplits,
-    int *__restrict__ blk_cnt, int *__restrict__ blk_list /*[blocks][nsplits]*/,
-    unsigned *__restrict__ work, unsigned *__restrict__ work_count,
-    const RowBounds rb = RowBounds{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr} /* ub != nullptr: the rows' bounds for a bounded pass */)
-{
-    static_assert(kCoarseQueries == 512, "one block of this kernel == one query block of k_nn_coarse");
-    if (honour_done && st->done) return;
-    const double *T = which ? st->total : st->delta;
-    const int i = blockIdx.x * kCoarseQueries + threadIdx.x;
-    double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308}, ub = 0.0;
-    if (i < n) {
-        const size_t si = perm ? perm[i] : (unsigned)i;
-        const double x = in[3 * si], y = in[3 * si + 1], z = in[3 * si + 2];
-        double p[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) p[r] = ((x * T[4 * r] + y * T[4 * r + 1]) + z * T[4 * r + 2]) + T[4 * r + 3];
-        out[3 * i] = p[0];
-        out[3 * i + 1] = p[1];
-        out[3 * i + 2] = p[2];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) lo[a] = hi[a] = p[a];
-        ub = __builtin_inf();
-        if (prev_idx) {
-            const int j = prev_idx[i];
-            if ((unsigned)j < (unsigned)m) ub = sqdist(tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2], p[0], p[1], p[2]);
-        }
-        if (rb.ub) { // the same distance, per row, for the bounded pass that follows (RowBatch::finish's images)
-            float ubf = __builtin_nanf(""), sqf = 0.f;
-            const bool fin = __builtin_isfinite(p[0]) && __builtin_isfinite(p[1]) && __builtin_isfinite(p[2]);
-            if (fin) {
-                ubf = (float)ub;
-                ubf = (double)ubf < ub ? __uint_as_float(__float_as_uint(ubf) + 1u) : ubf;
-                sqf = __builtin_amdgcn_sqrtf(ubf);
-                sqf = sqf < 3.0e38f ? __uint_as_float(__float_as_uint(sqf) + 2u) : sqf;
-            }
-            rb.ub[i] = fin ? ub : __builtin_inf();
-            rb.ubf[i] = ubf;
-            rb.sqf[i] = sqf;
-            rb.cnt[i] = 0;
-        }
-    }
-    __shared__ double red[8][7];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double l2 = __shfl_xor(lo[a], off, 64), h2 = __shfl_xor(hi[a], off, 64);
-            lo[a] = l2 < lo[a] ? l2 : lo[a];
-            hi[a] = h2 > hi[a] ? h2 : hi[a];
-        }
-        const double u2 = __shfl_xor(ub, off, 64);
-        ub = u2 > ub ? u2 : ub;
-    }
-    if (lane == 0) {
-        for (int a = 0; a < 3; ++a) {
-            red[wave][a] = lo[a];
-            red[wave][3 + a] = hi[a];
-        }
-        red[wave][6] = ub;
-    }
-    __syncthreads();
-    __shared__ BlockBounds sb;
-    if (threadIdx.x == 0) {
-        BlockBounds b;
-        for (int a = 0; a < 3; ++a) {
-            b.lo[a] = red[0][a];
-            b.hi[a] = red[0][3 + a];
-        }
-        b.ub = red[0][6];
-        for (int w = 1; w < 8; ++w) {
-            for (int a = 0; a < 3; ++a) {
-                b.lo[a] = red[w][a] < b.lo[a] ? red[w][a] : b.lo[a];
-                b.hi[a] = red[w][3 + a] > b.hi[a] ? red[w][3 + a] : b.hi[a];
-            }
-            b.ub = red[w][6] > b.ub ? red[w][6] : b.ub;
-        }
-        b.pad = 0.0;
-        sb = b;
-    }
-    __syncthreads();
-    // cull with the tighter of two bounds (see cull_block)
-    if (wave == 0) {
-        // A second bound that needs no previous neighbour (first pass, rows whose neighbour is
-        // unknown): every split holds a target, and that target is no farther from any query of
-        // the block than the largest distance between the two boxes.
-        double ub = sb.ub;
-        {
-            double far2 = __builtin_inf();
-            for (int s = lane; s < nsplits; s += 64) {
-                double f2 = 0.0;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const double f1 = sb.hi[a] - frames[s].lo[a], f3 = frames[s].hi[a] - sb.lo[a];
-                    const double f = f1 > f3 ? f1 : f3;
-                    f2 += f * f;
-                }
-                far2 = f2 < far2 ? f2 : far2;
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double o = __shfl_xor(far2, off, 64);
-                far2 = o < far2 ? o : far2;
-            }
-            far2 *= 1.0 + 1e-12;
-            ub = far2 < ub ? far2 : ub;
-        }
-        cull_block(blockIdx.x, sb.lo, sb.hi, ub, frames, nsplits, blk_cnt, blk_list, work, work_count, lane);
-    }
-}
-
-// Normal estimation with the pruned engine: the rows are the sorted targets themselves, so a
-// block is 512 consecutive sorted positions = 8 slots of 64.  A slot with at least k points
-// puts the k-th neighbour of each of its points (the point itself counts, kdtree.hpp:65-78)
-// within the diagonal of the slot's bounding box; the block's bound is the largest of its
-// slots' (infinite if one of them is too small to vouch for k neighbours).
-__global__ __launch_bounds__(kCoarseQueries) void k_knn_block_bounds(
-    const double *__restrict__ sorted, int m, int ms, int row0, int nrows, int kk,
-    const SplitFrame *__restrict__ frames, int nsplits, int *__restrict__ blk_cnt,
-    int *__restrict__ blk_list, unsigned *__restrict__ work, unsigned *__restrict__ work_count,
-    const double *__restrict__ t_row = nullptr /* the rows' own bounds (k_knn_prebound), indexed from the launch's first row: the block's bound is their largest */)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int local = blockIdx.x * kCoarseQueries + threadIdx.x;
-    const int j = row0 + local;
-    const bool valid = local < nrows && j < m;
-    double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
-    if (valid) {
-        lo[0] = hi[0] = ICPMI_SX(sorted, ms, j);
-        lo[1] = hi[1] = ICPMI_SY(sorted, ms, j);
-        lo[2] = hi[2] = ICPMI_SZ(sorted, ms, j);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double l2 = __shfl_xor(lo[a], off, 64), h2 = __shfl_xor(hi[a], off, 64);
-            lo[a] = l2 < lo[a] ? l2 : lo[a];
-            hi[a] = h2 > hi[a] ? h2 : hi[a];
-        }
-    }
-    // this wave's 64 rows are one slot of the sorted target only if the slot is complete in
-    // the cloud (row0 is a multiple of 64); rows past the chunk still belong to the slot
-    const int slot0 = row0 + blockIdx.x * kCoarseQueries + wave * 64;
-    const int in_cloud = slot0 < m ? (m - slot0 < 64 ? m - slot0 : 64) : 0;
-    const int here = __popcll(__ballot(valid));
-    double ub = 0.0;
-    if (here > 0) {
-        const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-        ub = (ex * ex + ey * ey) + ez * ez;
-        ub *= 1.0 + 1e-12;
-        // fewer rows here than the slot holds in the cloud (chunk edge), or fewer than k: no bound
-        if (here < in_cloud || in_cloud < kk || !(ub == ub)) ub = __builtin_inf();
-    }
-    if (t_row) { // every row's k-th neighbour lies within its own bound: the largest over the wave's rows serves them all
-        double t = valid ? t_row[local] : 0.0;
-        t = t == t ? t : __builtin_inf();
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double o = __shfl_xor(t, off, 64);
-            t = o > t ? o : t;
-        }
-        ub = here > 0 ? t * (1.0 + 1e-12) : 0.0;
-    }
-    __shared__ double red[8][7];
-    __shared__ double sbox[7];
-    if (lane == 0) {
-        for (int a = 0; a < 3; ++a) {
-            red[wave][a] = lo[a];
-            red[wave][3 + a] = hi[a];
-        }
-        red[wave][6] = ub;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double b[7];
-        for (int a = 0; a < 7; ++a) b[a] = red[0][a];
-        for (int w = 1; w < 8; ++w) {
-            for (int a = 0; a < 3; ++a) {
-                b[a] = red[w][a] < b[a] ? red[w][a] : b[a];
-                b[3 + a] = red[w][3 + a] > b[3 + a] ? red[w][3 + a] : b[3 + a];
-            }
-            b[6] = red[w][6] > b[6] ? red[w][6] : b[6];
-        }
-        for (int a = 0; a < 7; ++a) sbox[a] = b[a];
-    }
-    __syncthreads();
-    if (wave == 0) cull_block(blockIdx.x, sbox, sbox + 3, sbox[6], frames, nsplits, blk_cnt, blk_list, work, work_count, lane);
-}
+// (The culled engine's kernels -- box test per 64-row group, coarse pass over the surviving (group, split) pairs -- are in
+// nn_culled.h.)
 
 // ---- resolve ---------------------------------------------------------------------------------------
 __device__ __forceinline__ double px_sel(int a, double x, double y, double z) { return a == 0 ? x : (a == 1 ? y : z); }

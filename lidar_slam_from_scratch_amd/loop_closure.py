@@ -10,6 +10,8 @@ with the arithmetic behind a small backend object:
 """
 import numpy as np
 
+MAX_BATCH = 8   # ICPMI_MAX_BATCH (include/icp_mi355x.h): registrations one icpmi_align_batch call takes
+
 
 class LoopClosureConfig:
     """loop_closure.hpp:14-19"""
@@ -108,7 +110,8 @@ class LoopClosureDetector:
         verified, pos = 0, 0
         many = getattr(self.backend, "align_many", None)
         while pos < len(candidates) and verified < self.config.max_candidates:   # :97
-            chunk = candidates[pos:pos + (self.config.max_candidates - verified)]
+            # (at most MAX_BATCH side by side: icpmi_align_batch's limit; a larger max_candidates takes more rounds)
+            chunk = candidates[pos:pos + min(self.config.max_candidates - verified, MAX_BATCH)]
             pos += len(chunk)
             if many is not None and len(chunk) > 1:
                 outs = many(self._clouds[q], [self._clouds[c] for _, c in chunk], 30, 1e-6)

@@ -721,8 +721,8 @@ def test_profile_counters(gpu_ctx):
 
 @pytest.mark.parametrize("case", ["c3_small_20k", "lidar_pair", "far_start"])
 def test_pruned_engine_skips_blocks_and_keeps_the_result(case, oracle):
-    """ICPMI_SEARCH_MFMA_PRUNED culls (query block, target split) pairs with a bounding-box
-    test against each block's exact distance to its previous neighbours.  The cull is
+    """ICPMI_SEARCH_MFMA_PRUNED culls (64-row group, target split) pairs with a bounding-box
+    test against each group's exact distance to its previous neighbours (nn_culled.h).  The cull is
     conservative, so the correspondences -- hence error history, iteration count and pose
     -- are those of the all-pairs engine (sums are formed in Morton order of the source, so
     the last bits of the history may differ)."""
@@ -1039,11 +1039,14 @@ print(json.dumps(out))
 
 
 def test_bounded_pass_gives_the_unbounded_pass_bits():
-    """nn_bounded.h: from its second pass on the ICP loop searches behind the rows' previous matches -- the coarse
-    pass lists the slots under each row's bound instead of keeping its minima, the resolve scans the listed slots
-    against the previous match as incumbent, no certificate.  Against ICPMI_NN_BOUNDED=0 (every pass k_nn_coarse<0> +
-    k_nn_resolve / k_nn_resolve4) the correspondences, hence the partial rows, pose, history and counts must agree BIT
-    FOR BIT, for both resolve layouts (16 rows per wave above 32,768 rows, one per quarter-wave below) and both coarse
+    """nn_bounded.h: every pass of the ICP loop searches behind a bound per row -- the exact distance to the row's
+    previous match, in the first pass to the nearest sorted target around its place in the target's Morton order
+    (k_nn_prebound1, round 4) -- the coarse pass lists the slots under each row's bound instead of keeping its minima,
+    the resolve scans the listed slots against the bound's target as incumbent, no certificate.  Against
+    ICPMI_NN_BOUNDED=0 on the all-pairs engine (every pass k_nn_coarse<0> + k_nn_resolve / k_nn_resolve4) the
+    correspondences, hence the partial rows, pose, history and counts must agree BIT FOR BIT -- the all-pairs engine's
+    bounded passes AND the culled engine's (nn_culled.h: the same passes on the (64-row group, split) pairs within
+    reach; what AUTO runs on these targets) -- for both resolve layouts (16 rows per wave above 32,768 rows, one per quarter-wave below) and both coarse
     unit sizes: uniform clouds, a raw
     LiDAR-like frame pair, a cloud full of exact ties, a source with NaN / infinite rows, a start so far off that the
     bounds span the whole target (every row takes the exhaustive search behind the split boxes), and two ranks."""
@@ -1071,7 +1074,8 @@ cases["nan_rows"] = (s2, t, None, 5)
 T0 = synth.make_transform(np.array([0.3, -0.2, 0.25]), np.array([40.0, -25.0, 10.0]))
 cases["far_start"] = (s[:36000], t, T0, 4)
 out = {}
-ctx = capi.Context(device=0, profile=2)   # (2: the bounded passes report their statistics too)
+engine = int(sys.argv[1])
+ctx = capi.Context(device=0, profile=2, search=engine)   # (2: the bounded passes report their statistics too)
 for name, (src, tgt, init, iters) in cases.items():
     cfg = capi.Context.make_config(max_iterations=iters, tolerance=0.0, min_error=0.0, initial_transform=init)
     ctx.reset_profile()
@@ -1085,7 +1089,7 @@ group = icpdist.LocalGroup(2)
 s, t, _ = synth.c3_uniform(90000, seed=81, perm_seed=82)
 def body(rank):
     lo, hi = icpdist.shard_bounds(s.shape[0], 2, rank)
-    c = capi.Context(device=0)
+    c = capi.Context(device=0, search=engine)
     group.attach(c, rank)
     res, hist = c.align(s[lo:hi], t, capi.Context.make_config(max_iterations=4, tolerance=0.0, min_error=0.0))
     c.comm_finalize(); c.close()
@@ -1096,20 +1100,26 @@ out["two_ranks"] = {"T": r[0][0], "hist": r[0][1]}
 print(json.dumps(out))
 ''' % root
     legs = {}
-    for knob in ("0", "1"):
-        env = dict(os.environ, ICPMI_NN_BOUNDED=knob)
-        r = subprocess.run([sys.executable, "-c", child], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    for knob, engine in (("0", capi.SEARCH_MFMA_BF16), ("1", capi.SEARCH_MFMA_BF16), ("culled", capi.SEARCH_AUTO)):
+        env = dict(os.environ, ICPMI_NN_BOUNDED="0" if knob == "0" else "1")
+        r = subprocess.run([sys.executable, "-c", child, str(engine)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         legs[knob] = json.loads(r.stdout.strip().splitlines()[-1])
-    for name, v in legs["1"].items():
-        if name == "two_ranks":
-            continue
-        assert legs["0"][name].pop("bounded") == 0 and v.pop("bounded") == v["iters"]   # every pass but the first (+ the post-loop pass)
-        ex0, ex1 = legs["0"][name].pop("exhaustive"), v.pop("exhaustive")
-        if name == "far_start":
-            assert ex1 > 30000                                                    # the exhaustive path did run
+    for knob in ("1", "culled"):
+        for name, v in legs[knob].items():
+            if name == "two_ranks":
+                continue
+            assert v.pop("bounded") == v["iters"] + 1, (knob, name)   # every pass, the first and the post-loop pass included
+            ex1 = v.pop("exhaustive")
+            if name == "far_start":
+                assert ex1 > 30000, (knob, ex1)                        # the exhaustive path did run
+    for name, v in legs["0"].items():
+        if name != "two_ranks":
+            assert v.pop("bounded") == 0
+            v.pop("exhaustive")
     assert legs["0"] == legs["1"]
+    assert legs["0"] == legs["culled"]
 
 
 def test_align_batch_is_the_sequential_calls(gpu_ctx):

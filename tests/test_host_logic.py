@@ -1,0 +1,61 @@
+"""Host-side logic that needs no GPU: the loop-closure detector's candidate handling (loop_closure.hpp:66-126)."""
+import numpy as np
+
+from lidar_slam_from_scratch_amd import loop_closure as lc
+
+
+class _Res:
+    def __init__(self, ok):
+        self.transformation = np.eye(4)
+        self.converged, self.final_error, self.num_iterations = ok, 0.1 if ok else 1.0, 3
+
+
+class _FakeBackend:
+    """Twelve history frames all look like the query; `accept` says which candidate indices pass verification.
+    align_many refuses more than ICPMI_MAX_BATCH problems, like icpmi_align_batch (ICPMI_ERR_ARG)."""
+
+    def __init__(self, accept, batched=True):
+        self.accept, self.calls = set(accept), []
+        if not batched:
+            self.align_many = None
+
+    def scan_context(self, cloud):
+        return np.full((20, 60), float(cloud[0, 0]))
+
+    def distances(self, q, hist):
+        return np.array([0.01 * (k + 1) for k in range(len(hist))])   # candidate k at distance 0.01 (k + 1): sorted order = index order
+
+    def _one(self, target):
+        return _Res(int(target[0, 0]) in self.accept)
+
+    def align(self, source, target, max_iterations, tolerance):
+        self.calls.append(1)
+        return self._one(target)
+
+    def align_many(self, source, targets, max_iterations, tolerance):
+        assert len(targets) <= lc.MAX_BATCH, "icpmi_align_batch takes at most ICPMI_MAX_BATCH problems"
+        self.calls.append(len(targets))
+        return [self._one(t) for t in targets]
+
+
+def _run(backend, max_candidates):
+    det = lc.LoopClosureDetector(backend, lc.LoopClosureConfig(frame_gap=1, sc_distance_threshold=0.5, icp_fitness_threshold=0.3,
+                                                               max_candidates=max_candidates))
+    for k in range(13):
+        det.add_frame(np.full((4, 3), float(k)), k)
+    return det.detect()
+
+
+def test_more_candidates_than_one_batch_takes():
+    """max_candidates above ICPMI_MAX_BATCH must not send more than a batch's worth to align_many; the
+    outcome is the sequential loop's (loop_closure.hpp:96-123): candidates in Scan Context order until max_candidates
+    are ACCEPTED."""
+    accept = {0, 2, 3, 5, 6, 7, 8, 9, 10, 11}
+    b = _FakeBackend(accept)
+    found = _run(b, 10)
+    assert [r.match_frame for r in found] == sorted(accept)
+    assert max(b.calls) <= lc.MAX_BATCH and sum(b.calls) == 12
+    seq = _run(_FakeBackend(accept, batched=False), 10)
+    assert [r.match_frame for r in seq] == [r.match_frame for r in found]
+    # fewer wanted than offered: stops after the third ACCEPTED one, as the reference does
+    assert [r.match_frame for r in _run(_FakeBackend(accept), 3)] == [0, 2, 3]
