@@ -227,6 +227,9 @@ struct icpmi_ctx {
     int nn_splits = 0;
     int nn_ms = 0;                            // component stride of the SoA sorted target
     int grp_cap = 0;                          // groups a split's list in grp_items can hold
+    bool tickets_clean = false;               // the sum tree's tickets (ctx->partials) are known to be zero
+    const void *tickets_at = nullptr;         // ... where they were last
+    int tickets_n = 0;
     IcpState *d_state = nullptr;   // two of them (align_device alternates in the sharded loop)
     IcpState *h_state = nullptr;   // pinned
     double *h_hist = nullptr;      // pinned: the error history of the last call
@@ -625,7 +628,7 @@ int reserve_group_lists(icpmi_ctx *ctx, int splits, long groups)
 {
     int rc;
     const size_t per = ((size_t)splits + kGrpCntPad - 1) / kGrpCntPad * kGrpCntPad;
-    if ((rc = reserve(ctx, ctx->grp_cnt, sizeof(unsigned) * 2 * per + 2 * sizeof(unsigned long long)))) return rc;
+    if ((rc = reserve(ctx, ctx->grp_cnt, sizeof(unsigned) * 2 * per + 2 * sizeof(unsigned long long) + 4 * sizeof(unsigned)))) return rc;
     if ((rc = reserve(ctx, ctx->grp_items, sizeof(unsigned) * (size_t)splits * (size_t)std::max<long>(groups, 1)))) return rc;
     ctx->grp_cap = (int)std::max<long>(groups, 1);
     return ICPMI_OK;
@@ -640,30 +643,56 @@ unsigned long long *group_stats(const icpmi_ctx *ctx)
     const size_t per = ((size_t)ctx->nn_splits + kGrpCntPad - 1) / kGrpCntPad * kGrpCntPad;
     return (unsigned long long *)((unsigned *)ctx->grp_cnt.p + 2 * per);
 }
+// the coarse kernel's chunk counters (nn_culled.h), one per parity of the pass: a pass hands its chunks out through its own
+// and clears the other; behind the statistics
+unsigned *group_work(const icpmi_ctx *ctx, int parity) { return (unsigned *)(group_stats(ctx) + 2) + (parity & 1); }
 size_t group_cnt_bytes(const icpmi_ctx *ctx)
 {
     const size_t per = ((size_t)ctx->nn_splits + kGrpCntPad - 1) / kGrpCntPad * kGrpCntPad;
-    return sizeof(unsigned) * 2 * per + 2 * sizeof(unsigned long long);
+    return sizeof(unsigned) * 2 * per + 2 * sizeof(unsigned long long) + 4 * sizeof(unsigned);
 }
 // workgroups of k_nn_coarse_groups: the chip's resident set (two 8-wave workgroups per CU at 4 waves per SIMD); a
 // workgroup walks over the chunks blockIdx, blockIdx + grid, ...  ICPMI_GROUPS_GRID=<per CU> for tuning runs.
-int coarse_groups_grid(const icpmi_ctx *ctx)
+// ICPMI_GROUPS_WAVES=4|8: pairs per workgroup (8: two workgroups per CU; 4: four, half the operand reuse, finer rounds)
+int coarse_groups_waves()
+{
+    static const int w = [] {
+        const char *e = getenv("ICPMI_GROUPS_WAVES");
+        return e && e[0] == '4' ? 4 : 8;
+    }();
+    return w;
+}
+int coarse_groups_grid(const icpmi_ctx *ctx, int waves)
 {
     static const int per_cu = [] {
         if (const char *e = getenv("ICPMI_GROUPS_GRID")) {
             const long x = strtol(e, nullptr, 10);
             if (x >= 1 && x <= 64) return (int)x;
         }
-        return 2;
+        return 0;
     }();
-    return per_cu * ctx->cu_count;
+    return (per_cu ? per_cu : 16 / waves) * ctx->cu_count;
+}
+size_t coarse_groups_lds(int splits) { return sizeof(unsigned) * (2 * (size_t)splits + 1); }
+// Diagnostic build (-DICPMI_GROUPS_CLOCKS, scripts/groups_clock.py): the culled coarse pass of the ICP loop stamps its
+// workgroups' phases into the (idle) slot-minimum buffer; icpmi_debug_coarse_clocks copies them out.  Null in the product build.
+unsigned long long *groups_clock_buffer(icpmi_ctx *ctx)
+{
+#ifdef ICPMI_GROUPS_CLOCKS
+    if (reserve(ctx, ctx->slotmin, sizeof(unsigned long long) * kGroupStamps * 64 * (size_t)ctx->cu_count) != ICPMI_OK) return nullptr;
+    return (unsigned long long *)ctx->slotmin.p;
+#else
+    (void)ctx;
+    return nullptr;
+#endif
 }
 
 // `bounded`: d_idx holds the rows' matches of the previous pass and the kernel that moved the rows has left their bounds
 // in ctx->nn_lists (RowBounds, kernels.h; nn_bounded.h)
 int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx, double *d_d2,
                    const IcpState *st, const double *d_tgt = nullptr, const double *d_nrm = nullptr,
-                   double *d_partials = nullptr, int pruned_pass = -1, bool bounded = false)
+                   double *d_partials = nullptr, int pruned_pass = -1, bool bounded = false,
+                   const SumTree tree = SumTree{nullptr, nullptr, 0})
 {
     const int splits = ctx->nn_splits;
     int rc;
@@ -687,10 +716,17 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
                 // group's bound is the largest of its rows'); pass p reads the lists counted in set p & 1 and clears the other
                 const GroupLists cur = group_lists(ctx, pruned_pass & 1), nxt = group_lists(ctx, (pruned_pass + 1) & 1);
                 const long groups = (n + kGroupRows - 1) / kGroupRows;
-                hipLaunchKernelGGL((k_nn_coarse_groups<false, kCoarseWaves>), dim3(coarse_groups_grid(ctx)), dim3(kCoarseThreads), 0, ctx->stream,
-                                   d_qry, n, (size_t)0, (const uint4 *)ctx->bpack.p, frames, splits, (const unsigned *)cur.items, cur.cap,
-                                   (const unsigned *)cur.cnt, nxt.cnt, ctx->opt.profile ? group_stats(ctx) : (unsigned long long *)nullptr,
-                                   (unsigned long long)(groups * splits), st, kl);
+#define ICPMI_GROUPS_ARGS                                                                                                              \
+    d_qry, n, (size_t)0, (const uint4 *)ctx->bpack.p, frames, splits, (const unsigned *)cur.items, cur.cap, (const unsigned *)cur.cnt, \
+        nxt.cnt, ctx->opt.profile ? group_stats(ctx) : (unsigned long long *)nullptr, (unsigned long long)(groups * splits), st, kl, \
+        group_work(ctx, pruned_pass & 1), group_work(ctx, (pruned_pass + 1) & 1), groups_clock_buffer(ctx)
+                if (coarse_groups_waves() == 4)
+                    hipLaunchKernelGGL((k_nn_coarse_groups<false, 4>), dim3(coarse_groups_grid(ctx, 4)), dim3(256), coarse_groups_lds(splits), ctx->stream,
+                                       ICPMI_GROUPS_ARGS);
+                else
+                    hipLaunchKernelGGL((k_nn_coarse_groups<false, 8>), dim3(coarse_groups_grid(ctx, 8)), dim3(512), coarse_groups_lds(splits), ctx->stream,
+                                       ICPMI_GROUPS_ARGS);
+#undef ICPMI_GROUPS_ARGS
             } else if (coarse_half_units(ctx, n, splits)) {
                 constexpr int per = kCoarseQueries / kCoarseQT; // queries per workgroup with one tile per wave
                 hipLaunchKernelGGL((k_nn_coarse_bounded<1, kCoarseWaves>), dim3((n + per - 1) / per, splits), dim3(kCoarseThreads), 0,
@@ -707,7 +743,7 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, splits, frames, (const double *)ub_row, (const int *)cnt_row, \
         (const unsigned *)ent_row, d_idx, ctx->opt.profile >= 2 ? counters : (unsigned long long *)nullptr, d_tgt, d_nrm, d_partials, st
         switch (resolve_waves(n)) {
-        case 0: hipLaunchKernelGGL(k_nn_resolve_bounded, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
+        case 0: hipLaunchKernelGGL(k_nn_resolve_bounded, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_BOUNDED_ARGS, tree); break;
         case 4: hipLaunchKernelGGL(k_nn_resolve4_bounded<4>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
         case 8: hipLaunchKernelGGL(k_nn_resolve4_bounded<8>, dim3(resolve_blocks(n)), dim3(512), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
         default: hipLaunchKernelGGL(k_nn_resolve4_bounded<16>, dim3(resolve_blocks(n)), dim3(1024), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
@@ -739,8 +775,8 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits, frames,  \
         (const NnFrame *)ctx->nn_misc.p, d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, blk_cnt, blk_list, st
     switch (resolve_waves(n)) {
-    case 0: hipLaunchKernelGGL(k_nn_resolve<16>, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
-    case -32: hipLaunchKernelGGL(k_nn_resolve<32>, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
+    case 0: hipLaunchKernelGGL(k_nn_resolve<16>, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_RESOLVE_ARGS, tree); break;
+    case -32: hipLaunchKernelGGL(k_nn_resolve<32>, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_RESOLVE_ARGS, tree); break;
     case 4: hipLaunchKernelGGL(k_nn_resolve4<4>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     case 8: hipLaunchKernelGGL(k_nn_resolve4<8>, dim3(resolve_blocks(n)), dim3(512), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     default: hipLaunchKernelGGL(k_nn_resolve4<16>, dim3(resolve_blocks(n)), dim3(1024), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
@@ -871,12 +907,19 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                     const GroupLists gl = group_lists(ctx, 0);
                     const int groups = (nq + kGroupRows - 1) / kGroupRows;
                     HIP_TRY(ctx, hipMemsetAsync(ctx->grp_cnt.p, 0, group_cnt_bytes(ctx), s));
-                    hipLaunchKernelGGL(k_knn_group_cull, dim3((groups + 3) / 4), dim3(256), 0, s, sorted, m, ctx->nn_ms, (int)c0, nq,
+                    hipLaunchKernelGGL(k_knn_group_cull, dim3((groups + 15) / 16), dim3(1024), 0, s, sorted, m, ctx->nn_ms, (int)c0, nq,
                                        (const double *)t_row, frames, splits, gl);
-                    hipLaunchKernelGGL((k_nn_coarse_groups<true, kCoarseWaves>), dim3(coarse_groups_grid(ctx)), dim3(kCoarseThreads), 0, s,
-                                       sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, splits,
-                                       (const unsigned *)gl.items, gl.cap, (const unsigned *)gl.cnt, (unsigned *)nullptr,
-                                       (unsigned long long *)nullptr, 0ull, (const IcpState *)nullptr, kl);
+#define ICPMI_GROUPS_ARGS                                                                                                                   \
+    sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, splits, (const unsigned *)gl.items, gl.cap,                  \
+        (const unsigned *)gl.cnt, (unsigned *)nullptr, (unsigned long long *)nullptr, 0ull, (const IcpState *)nullptr, kl,               \
+        group_work(ctx, 0), (unsigned *)nullptr
+                    if (coarse_groups_waves() == 4)
+                        hipLaunchKernelGGL((k_nn_coarse_groups<true, 4>), dim3(coarse_groups_grid(ctx, 4)), dim3(256), coarse_groups_lds(splits), s,
+                                           ICPMI_GROUPS_ARGS);
+                    else
+                        hipLaunchKernelGGL((k_nn_coarse_groups<true, 8>), dim3(coarse_groups_grid(ctx, 8)), dim3(512), coarse_groups_lds(splits), s,
+                                           ICPMI_GROUPS_ARGS);
+#undef ICPMI_GROUPS_ARGS
                 } else if (coarse_half_units(ctx, nq, splits)) {
                     constexpr int per = kCoarseQueries / kCoarseQT;
                     hipLaunchKernelGGL((k_nn_coarse_rows<1, kCoarseWaves>), dim3((nq + per - 1) / per, splits), dim3(kCoarseThreads), 0,
@@ -1157,8 +1200,36 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // small clouds: one kernel per iteration for the rows' work (icp_small.h), then k_finish_step
     const bool small = !sharded_run && n > 0 && n <= small_max_queries() && small_target(ctx);
     const int rblocks = small ? (n + kSmallQ - 1) / kSmallQ : (fused ? resolve_blocks(n) : reduce_blocks(ctx, n));
-    if ((rc = reserve(ctx, ctx->partials, sizeof(double) * kSumsStride * (size_t)rblocks))) return rc;
+    // the large-cloud resolve kernels add their partial rows up in groups of kSumGroup (SumTree, nn_mfma.h): the step kernels
+    // then sum rblocks2 rows (ICPMI_SUM_TREE=0: one level, round 3's order of additions -- the A/B knob)
+    static const bool sum_tree_on = [] {
+        const char *e = getenv("ICPMI_SUM_TREE");
+        return !(e && e[0] == '0' && e[1] == '\0');
+    }();
+    const bool sum_tree = sum_tree_on && fused && !small && n > 0 && resolve_waves(n) <= 0;
+    const int rblocks2 = sum_tree ? (rblocks + kSumGroup - 1) / kSumGroup : 0;
+    {
+        const size_t cap_before = ctx->partials.cap;
+        if ((rc = reserve(ctx, ctx->partials, sizeof(double) * kSumsStride * ((size_t)rblocks + (size_t)rblocks2) + sizeof(unsigned) * (size_t)rblocks2 + 64))) return rc;
+        if (ctx->partials.cap != cap_before) ctx->tickets_clean = false;
+    }
     double *partials = (double *)ctx->partials.p;
+    SumTree tree{nullptr, nullptr, 0};
+    if (sum_tree) {
+        tree = SumTree{partials + kSumsStride * (size_t)rblocks, (unsigned *)(partials + kSumsStride * ((size_t)rblocks + (size_t)rblocks2)), rblocks};
+        // the tickets are back at zero after every completed launch; a buffer fresh from the allocator, one last used with
+        // another layout, or a call that did not finish leaves them unknown
+        if (!ctx->tickets_clean || ctx->tickets_at != (const void *)tree.tickets || ctx->tickets_n != rblocks2)
+            HIP_TRY(ctx, hipMemsetAsync(tree.tickets, 0, sizeof(unsigned) * (size_t)rblocks2, s));
+        ctx->tickets_at = tree.tickets;
+        ctx->tickets_n = rblocks2;
+        ctx->tickets_clean = false; // (until this call has come back)
+    }
+    else
+        ctx->tickets_clean = false; // (this call's rows may lie where another layout kept its tickets)
+    // what the step kernels sum: the second-level rows where there are any
+    const double *fin_rows = sum_tree ? tree.rows2 : partials;
+    const int fin_blocks = sum_tree ? rblocks2 : rblocks;
 
     // normals of the target (icp.hpp:169-171).  With several ranks each computes a slice of
     // rows against the full target and the slices are all-gathered.
@@ -1252,7 +1323,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         StageTimer t(ctx, ST_TRANSFORM);
         hipLaunchKernelGGL(k_transform, dim3(std::min(2048, (n + 255) / 256)), dim3(256), 0, s, d_src, cur, n, st, 1, 0, src_perm);
         if (bounded_loop) // the first pass's incumbents and bounds (and, culled engine, its group lists: set 0)
-            hipLaunchKernelGGL(k_nn_prebound1, dim3((n + 255) / 256), dim3(256), 0, s, (const double *)cur, n, (const double *)ctx->tgt_sorted.p,
+            hipLaunchKernelGGL(k_nn_prebound1, dim3((n + kPreThreads - 1) / kPreThreads), dim3(kPreThreads), 0, s, (const double *)cur, n, (const double *)ctx->tgt_sorted.p,
                                (const unsigned *)ctx->sort_keys.p + (size_t)m /* the sorted keys */,
                                (const unsigned *)ctx->sort_keys.p + 3 * (size_t)m, m, ctx->nn_ms, (const NnFrame *)ctx->nn_misc.p, idx, rb,
                                frames, splits, pruned ? group_lists(ctx, 0) : GroupLists{nullptr, nullptr, 0});
@@ -1294,7 +1365,8 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         const bool fuse_finish = !sharded && n > 0 && !final_pass && fuse_finish_enabled();
         if (n > 0 && fused) {
             if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, st, d_tgt, nrm, partials,
-                                     pruned ? pass_no : -1, bounded_loop /* incumbents in idx, bounds in place: from k_nn_prebound1 or the kernel that moved the rows */))) return r2;
+                                     pruned ? pass_no : -1, bounded_loop /* incumbents in idx, bounds in place: from k_nn_prebound1 or the kernel that moved the rows */,
+                                     tree))) return r2;
             ++pass_no;
         } else if (n > 0) {
             if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, st))) return r2;
@@ -1306,7 +1378,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                 hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, cur, n, d_tgt, m, nrm, idx, partials,
                                    st);
             if (sharded) {
-                hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
+                hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), 0, s, fin_rows, fin_blocks, n,
                                    st);
                 {
                     StageTimer tx(ctx, ST_EXCHANGE); // the per-pass all-reduce alone (30 doubles; RCCL on the library's stream)
@@ -1331,15 +1403,15 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
                 IcpState *other = st == ctx->d_state ? ctx->d_state + 1 : ctx->d_state;
                 if (pruned) // (+ the group lists of the coming pass: set pass_no & 1)
                     hipLaunchKernelGGL(k_finish_step_transform_cull, dim3(finish_transform_blocks(n)), dim3(kFinishThreads), 0, s,
-                                       (const double *)partials, rblocks, n, (const double *)cur, cur, n, (const IcpState *)st, other,
+                                       fin_rows, fin_blocks, n, (const double *)cur, cur, n, (const IcpState *)st, other,
                                        hist, progress, ticket, rb, frames, splits, group_lists(ctx, pass_no & 1));
                 else
                     hipLaunchKernelGGL(k_finish_step_transform, dim3(finish_transform_blocks(n)), dim3(kFinishThreads), 0, s,
-                                       (const double *)partials, rblocks, n, (const double *)cur, cur, n,
+                                       fin_rows, fin_blocks, n, (const double *)cur, cur, n,
                                        (const IcpState *)st, other, hist, progress, ticket, rb);
                 st = other;
             } else {
-                hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(kFinishThreads), 0, s, partials, rblocks, n,
+                hipLaunchKernelGGL(k_finish_step, dim3(1), dim3(kFinishThreads), 0, s, fin_rows, fin_blocks, n,
                                    st, hist, final_pass, progress, ticket);
             }
         }
@@ -1456,6 +1528,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         return fail(ctx, ICPMI_ERR_RCCL, "the ranks of this sharded run disagreed on the end of the loop "
                                          "(different icpmi_config per rank, or an exchange that is not bit-identical on every rank)");
 
+    ctx->tickets_clean = true; // (every queued resolve launch has completed: its groups' tickets are back at zero)
     memcpy(result->transformation, hs->total, sizeof(double) * 16); // icp.hpp:254
     result->converged = hs->converged;
     result->num_iterations = hs->hist_len - 1;                      // icp.hpp:255
@@ -1999,6 +2072,7 @@ int icpmi_solve_point_to_plane(icpmi_ctx *ctx, const double *source_xyz, const d
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(IcpState), s));
     {
         StageTimer t(ctx, ST_REDUCE);
+        ctx->tickets_clean = false; // (the rows below may lie where a registration's sum tree kept its tickets)
         hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, (const double *)ctx->stage_a.p, n,
                            (const double *)ctx->stage_b.p, n, (const double *)ctx->stage_c.p,
                            (const int *)nullptr, (double *)ctx->partials.p, (const IcpState *)nullptr);
@@ -3060,7 +3134,7 @@ extern "C" int icpmi_debug_loop_rows(icpmi_ctx *ctx, int32_t *idx_out, double *c
 }
 #endif
 
-#if defined(ICPMI_COARSE_CLOCKS) || defined(ICPMI_SMALL_CLOCKS)
+#if defined(ICPMI_COARSE_CLOCKS) || defined(ICPMI_SMALL_CLOCKS) || defined(ICPMI_GROUPS_CLOCKS)
 // diagnostic build only: the stamps of the last all-pairs 1-NN pass (4 words per workgroup:
 // s_memtime, s_memrealtime at its start and at its end)
 int icpmi_debug_coarse_clocks(icpmi_ctx *ctx, unsigned long long *out, int64_t words)

@@ -13,7 +13,7 @@
 //     gap^2(box(g), box(s)) <= max over the group's rows of ub: every other (group, split) pair is culled -- strictly
 //     greater, with a margin for the test's own roundings, so not even a target at EQUAL distance is lost and the
 //     lowest-index tie rule survives;
-//   * the surviving pairs are appended to one list per SPLIT (wave_cull), and k_nn_coarse_groups runs the MFMA unit of
+//   * the surviving pairs are appended to one list per SPLIT (block_cull), and k_nn_coarse_groups runs the MFMA unit of
 //     nn_mfma.h on them: a workgroup takes eight groups of ONE split's list -- any eight, they need not be neighbours --
 //     stages the split's operands through LDS once and gives each wave one group.  The epilogue is MODE 2's: the slots
 //     under the row's per-split threshold tau_s(ub(row)) are listed per row, and k_nn_resolve_bounded (nn_bounded.h) scans
@@ -30,6 +30,7 @@
 namespace icpmi {
 
 constexpr int kGroupRows = 64;          // rows per group: one wave's two 32-row MFMA tiles
+constexpr int kGroupStamps = 12;        // diagnostic build (-DICPMI_GROUPS_CLOCKS): words per workgroup of k_nn_coarse_groups
 constexpr int kCullMaxSplits = 4096;    // splits whose chunk prefix fits the coarse kernel's LDS (8.4M targets); beyond: all pairs
 static_assert(kGroupRows == kTile * kCoarseQT, "a group is what one wave of the coarse unit takes");
 
@@ -40,14 +41,25 @@ struct GroupLists {
     int cap;          // groups a list can hold = groups of the pass (a group enters a split's list at most once)
 };
 
-// The box test, by one whole wave for group g: (lo, hi, ub) are the lanes' own rows (a lane without a row: lo = +big,
-// hi = -big, ub = 0); reduced here over the wave.  `ub` may be +Inf (a row without any bound) or NaN-free by the
-// caller's care; an infinite bound is replaced by the one that needs no match at all: every split holds a target, and
-// that target is no farther from any row of the group than the largest distance between the two boxes.
-__device__ __forceinline__ void wave_cull(const int g, double (&lo)[3], double (&hi)[3], double ub,
-                                          const SplitFrame *__restrict__ frames, const int nsplits, const GroupLists &gl,
-                                          const int lane)
+// The box test for the groups of a workgroup.  Per wave: (lo, hi, ub) are the lanes' own rows of group g (a lane without a
+// row: lo = +big, hi = -big, ub = 0), reduced here over the wave.  A bound of +Inf (a row without any) is replaced by the one
+// that needs no match at all: every split holds a target, and that target is no farther from any row of the group than
+// the largest distance between the two boxes.
+// The same test for all the groups of a workgroup at once (16 in a 1024-thread one), with ONE global atomic per (workgroup, split that
+// any of its groups reaches) instead of one per (group, split): the workgroup counts its survivors per split in LDS,
+// reserves a run in each split's list, and its waves place their groups inside the runs.  (With an atomic per pair the
+// ~7,400 pairs of a C3 pass queued up on 49 addresses: 150 returning atomics per address, one after the other in the L2 --
+// the kernel took 29.6 us against the 16.9 of the form without lists.)  Must be called by every wave of the workgroup
+// (four barriers); a wave without rows passes lo = +big, hi = -big.
+struct CullLds {
+    unsigned cnt[kCullMaxSplits];   // survivors of this workgroup per split, then the cursor inside its run
+};
+__device__ __forceinline__ void block_cull(CullLds &lds, const int g, double (&lo)[3], double (&hi)[3], double ub,
+                                           const SplitFrame *__restrict__ frames, const int nsplits, const GroupLists &gl,
+                                           const int lane)
 {
+    __syncthreads(); // (a workgroup with several rounds of rows: the previous round's cursors are no longer in use)
+    for (int s = threadIdx.x; s < nsplits; s += blockDim.x) lds.cnt[s] = 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -59,8 +71,8 @@ __device__ __forceinline__ void wave_cull(const int g, double (&lo)[3], double (
         const double u2 = __shfl_xor(ub, off, 64);
         ub = u2 > ub ? u2 : ub;
     }
-    if (!(lo[0] <= hi[0])) return; // no finite row in the group: nothing to search for
-    if (!(ub < 1.0e300)) {
+    const bool any = lo[0] <= hi[0]; // a finite row in the group
+    if (any && !(ub < 1.0e300)) {
         double far2 = __builtin_inf();
         for (int s = lane; s < nsplits; s += 64) {
             double f2 = 0.0;
@@ -70,31 +82,38 @@ __device__ __forceinline__ void wave_cull(const int g, double (&lo)[3], double (
                 const double f = f1 > f3 ? f1 : f3;
                 f2 += f * f;
             }
-            far2 = f2 < far2 ? f2 : far2; // (an empty split's inverted box gives a huge value or NaN: never the minimum)
+            far2 = f2 < far2 ? f2 : far2;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const double o = __shfl_xor(far2, off, 64);
             far2 = o < far2 ? o : far2;
         }
-        ub = far2 * (1.0 + 1e-12); // (+Inf when no split has a finite target: everything is kept, nothing is found)
+        ub = far2 * (1.0 + 1e-12);
     }
-    for (int s0 = 0; s0 < nsplits; s0 += 64) {
-        const int s = s0 + lane;
-        if (s < nsplits) {
-            double g2 = 0.0;
+    auto reach = [&](const int s) -> bool {
+        double g2 = 0.0;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double g1 = lo[a] - frames[s].hi[a], g3 = frames[s].lo[a] - hi[a];
-                const double gg = g1 > g3 ? g1 : g3;
-                g2 += gg > 0.0 ? gg * gg : 0.0;
-            }
-            if (!(g2 * (1.0 - 1e-12) > ub * (1.0 + 1e-12))) {
-                const unsigned pos = atomicAdd(gl.cnt + s, 1u);
-                gl.items[(size_t)s * gl.cap + pos] = (unsigned)g;
-            }
+        for (int a = 0; a < 3; ++a) {
+            const double g1 = lo[a] - frames[s].hi[a], g3 = frames[s].lo[a] - hi[a];
+            const double gg = g1 > g3 ? g1 : g3;
+            g2 += gg > 0.0 ? gg * gg : 0.0;
         }
+        return !(g2 * (1.0 - 1e-12) > ub * (1.0 + 1e-12));
+    };
+    __syncthreads(); // counters cleared
+    if (any)
+        for (int s = lane; s < nsplits; s += 64)
+            if (reach(s)) atomicAdd(&lds.cnt[s], 1u);
+    __syncthreads(); // counted
+    for (int s = threadIdx.x; s < nsplits; s += blockDim.x) {
+        const unsigned c = lds.cnt[s];
+        if (c) lds.cnt[s] = atomicAdd(gl.cnt + s, c); // the run [base, base + c) of split s's list is this workgroup's
     }
+    __syncthreads(); // runs reserved: cnt[] now holds each run's cursor
+    if (any)
+        for (int s = lane; s < nsplits; s += 64)
+            if (reach(s)) gl.items[(size_t)s * gl.cap + atomicAdd(&lds.cnt[s], 1u)] = (unsigned)g;
 }
 
 // What a kernel that moves rows leaves for the bounded pass that follows (RowBatch::finish's images, kernels.h), for one
@@ -133,14 +152,16 @@ __device__ __forceinline__ void row_bound_store(const RowBounds &rb, const int i
 // neighbours too (the source is in Morton order), so their windows overlap and the loads mostly hit the same lines.
 // With group lists the wave then culls the splits for its 64 rows (pruned engine).
 constexpr int kPreWindow = 128;
-__global__ __launch_bounds__(256) void k_nn_prebound1(const double *__restrict__ cur, int n, const double *__restrict__ sorted,
+constexpr int kPreThreads = 512;
+__global__ __launch_bounds__(kPreThreads) void k_nn_prebound1(const double *__restrict__ cur, int n, const double *__restrict__ sorted,
                                                       const unsigned *__restrict__ keys_sorted, const unsigned *__restrict__ perm,
                                                       int m, int ms, const NnFrame *__restrict__ frame, int *__restrict__ idx,
                                                       const RowBounds rb, const SplitFrame *__restrict__ frames, int nsplits,
                                                       const GroupLists gl)
 {
+    __shared__ CullLds cl;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * kPreThreads + threadIdx.x;
     const bool valid = i < n;
     const int ic = valid ? i : n - 1;
     const double px = cur[3 * ic], py = cur[3 * ic + 1], pz = cur[3 * ic + 2];
@@ -186,7 +207,7 @@ __global__ __launch_bounds__(256) void k_nn_prebound1(const double *__restrict__
     const int bjc = have ? bj : 0;
     row_bound_store(rb, i, valid, px, py, pz, have, ICPMI_SX(sorted, ms, bjc), ICPMI_SY(sorted, ms, bjc), ICPMI_SZ(sorted, ms, bjc), lo, hi,
                     ubg);
-    if (gl.cnt) wave_cull(i / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
+    if (gl.cnt) block_cull(cl, i / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
 }
 
 // ---- the pose update of the rows with the next pass's bounds and group lists -------------------------------------------
@@ -198,6 +219,7 @@ __global__ __launch_bounds__(256) void k_transform_cull(const double *in, const 
                                                         const RowBounds rb, const SplitFrame *__restrict__ frames, int nsplits,
                                                         const GroupLists gl)
 {
+    __shared__ CullLds cl;
     if (honour_done && st->done) return;
     const double *T = which ? st->total : st->delta;
     const int lane = threadIdx.x & 63;
@@ -220,7 +242,7 @@ __global__ __launch_bounds__(256) void k_transform_cull(const double *in, const 
     if (!rb.ub) return;
     double lo[3], hi[3], ubg;
     row_bound_store(rb, i, valid, p[0], p[1], p[2], have, t[0], t[1], t[2], lo, hi, ubg);
-    if (gl.cnt) wave_cull(i / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
+    if (gl.cnt) block_cull(cl, i / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
 }
 
 // Single GPU: final sum + step + pose update of the rows (k_finish_step_transform, kernels.h) + the rows' bounds and the
@@ -232,6 +254,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform_cull(
     int nsplits, const GroupLists gl)
 {
     __shared__ IcpState ls, sums; // `sums`: only its sums[] are used
+    __shared__ CullLds cl;
     const int lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * kFinishThreads + threadIdx.x, stride = gridDim.x * kFinishThreads;
     // everything that does not depend on the state is requested first: this thread's first row, its previous match and
@@ -265,8 +288,9 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform_cull(
     const double r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3];
     const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
     const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
-    // (wave-uniform trip count: a wave's 64 rows start at a multiple of 64, so the wave's first lane decides)
-    for (int base = i0; base - lane < n; base += stride) {
+    // (workgroup-uniform trip count -- block_cull has barriers: the workgroup's first row decides; a wave past the end
+    // of the rows brings an empty box)
+    for (int base = i0; base - (int)threadIdx.x < n; base += stride) {
         if (base != i0) load_row(base);
         const bool valid = base < n;
         const double px = ((x * r00 + y * r01) + z * r02) + t0;
@@ -279,7 +303,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform_cull(
         }
         double lo[3], hi[3], ubg;
         row_bound_store(rb, base, valid, px, py, pz, have, tx, ty, tz, lo, hi, ubg);
-        wave_cull((base - lane) / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
+        block_cull(cl, (base - lane) / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
     }
 }
 
@@ -290,6 +314,7 @@ __global__ __launch_bounds__(256) void k_step_transform_cull(const double *in, d
                                                              const SplitFrame *__restrict__ frames, int nsplits, const GroupLists gl)
 {
     __shared__ IcpState ls;
+    __shared__ CullLds cl;
     const int lane = threadIdx.x & 63;
     const int i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
     double x = 0.0, y = 0.0, z = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
@@ -324,7 +349,7 @@ __global__ __launch_bounds__(256) void k_step_transform_cull(const double *in, d
     const double r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3];
     const double r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7];
     const double r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
-    for (int base = i0; base - lane < n; base += stride) {
+    for (int base = i0; base - (int)threadIdx.x < n; base += stride) { // (workgroup-uniform trip count: block_cull has barriers)
         if (base != i0) load_row(base);
         const bool valid = base < n;
         const double px = ((x * r00 + y * r01) + z * r02) + t0;
@@ -337,21 +362,21 @@ __global__ __launch_bounds__(256) void k_step_transform_cull(const double *in, d
         }
         double lo[3], hi[3], ubg;
         row_bound_store(rb, base, valid, px, py, pz, have, tx, ty, tz, lo, hi, ubg);
-        wave_cull((base - lane) / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
+        block_cull(cl, (base - lane) / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
     }
 }
 
 // ---- normal estimation: the groups are runs of 64 sorted target rows, their bound the largest of the rows' own ----------
 // (k_knn_prebound's T: the k-th neighbour of every row lies within it).  One wave per group; rows = sorted positions
 // row0 .. row0 + nrows, groups and bounds numbered from the launch's first row (row0 a multiple of 64).
-__global__ __launch_bounds__(256) void k_knn_group_cull(const double *__restrict__ sorted, int m, int ms, int row0, int nrows,
+__global__ __launch_bounds__(1024) void k_knn_group_cull(const double *__restrict__ sorted, int m, int ms, int row0, int nrows,
                                                         const double *__restrict__ t_row, const SplitFrame *__restrict__ frames,
                                                         int nsplits, const GroupLists gl)
 {
+    __shared__ CullLds cl;
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = blockIdx.x * 16 + (threadIdx.x >> 6);
     const int local = g * kGroupRows + lane;
-    if (g * kGroupRows >= nrows) return;
     const int j = row0 + local;
     const bool valid = local < nrows && j < m;
     double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308}, ub = 0.0;
@@ -363,28 +388,42 @@ __global__ __launch_bounds__(256) void k_knn_group_cull(const double *__restrict
             ub = t == t ? t : __builtin_inf();
         }
     }
-    wave_cull(g, lo, hi, ub, frames, nsplits, gl, lane);
+    block_cull(cl, g, lo, hi, ub, frames, nsplits, gl, lane); // (a wave past the last group brings an empty box)
 }
 
 // ---- the coarse pass over the group lists ------------------------------------------------------------------------------
-// One (row group, split) pair per wave, eight pairs of the SAME split per workgroup: the unit of nn_mfma.h (operands of the
+// One (row group, split) pair per wave, WAVES pairs of the SAME split per workgroup: the unit of nn_mfma.h (operands of the
 // split staged through LDS in two chunks, 128 MFMAs per wave, MODE 2 epilogue) with each wave's rows taken from the
 // split's list.  A fixed grid strides over the chunks of all lists: chunk c belongs to the split s with
-// pre[s] <= c < pre[s + 1], pre = the running sum of ceil(cnt[s] / 8) -- formed by every workgroup for itself (a few
+// pre[s] <= c < pre[s + 1], pre = the running sum of ceil(cnt[s] / WAVES) -- formed by every workgroup for itself (a few
 // dozen loads and one wave scan), so no kernel sits between the box test and this one.  `cnt_next`: the counters the NEXT
 // pass's lists will be appended to (by the kernel that moves the rows after this pass); nobody reads or writes them while
 // this kernel runs, so they are cleared here.
+// The chunks are handed out DYNAMICALLY: a workgroup starts on chunk blockIdx and takes its next one from a counter
+// (`work`: this pass's; `work_next`: the next pass's, cleared here).  With a static stride the two workgroups of a CU do not
+// share it evenly -- the SIMDs' arbiter serves the older workgroup's waves first (in-kernel stamps, scripts/groups_clock.py:
+// first chunk 14.8 us in the workgroup that arrived first, 26 us in the other) -- so the 84 late workgroups that also
+// had a second chunk were a tail of 12 us behind everybody else: 42 us where 30 do.
+// Dynamic LDS: (2 nsplits + 1) words.
 template <bool QSOA, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nn_coarse_groups(
     const double *__restrict__ qry, int n, size_t qstride, const uint4 *__restrict__ Bpack, const SplitFrame *__restrict__ frames,
     int nsplits, const unsigned *__restrict__ items, int cap, const unsigned *__restrict__ cnt, unsigned *__restrict__ cnt_next,
     unsigned long long *__restrict__ stats /* [0] += pairs run, [1] += pairs of the pass (may be null) */, unsigned long long pairs_total,
-    const IcpState *__restrict__ st, const KnnLists kl)
+    const IcpState *__restrict__ st, const KnnLists kl, unsigned *__restrict__ work, unsigned *__restrict__ work_next,
+    unsigned long long *__restrict__ clocks = nullptr /* diagnostic build only */)
 {
-    if (st && st->done) return;
+#ifdef ICPMI_GROUPS_CLOCKS /* scripts/groups_clock.py: 100 MHz stamps per workgroup -- entry, lists known, each chunk's ends, exit */
+    unsigned long long stamp[kGroupStamps];
+    for (int k = 0; k < kGroupStamps; ++k) stamp[k] = 0;
+    stamp[0] = __builtin_amdgcn_s_memrealtime();
+    int nchunk = 0;
+#endif
     __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
-    __shared__ unsigned pre[kCullMaxSplits + 1];
+    extern __shared__ unsigned dyn_lds[];
+    unsigned *pre = dyn_lds, *lcnt = dyn_lds + nsplits + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int done = st ? st->done : 0;
     if (wave == 0) {
         unsigned run = 0, listed = 0;
         for (int s0 = 0; s0 < nsplits; s0 += 64) {
@@ -398,38 +437,78 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
                 inc += lane >= off ? o : 0u;
                 tot += __shfl_xor(tot, off, 64);
             }
-            if (s < nsplits) pre[s] = run + inc - ch;
+            if (s < nsplits) {
+                pre[s] = run + inc - ch;
+                lcnt[s] = c;
+            }
             run += __shfl(inc, 63, 64);
             listed += tot;
         }
         if (lane == 0) {
             pre[nsplits] = run;
-            if (blockIdx.x == 0 && stats) {
+            if (blockIdx.x == 0 && stats && !done) {
                 atomicAdd(stats, (unsigned long long)listed);
                 atomicAdd(stats + 1, pairs_total);
             }
         }
     }
+    if (done) return; // (the whole grid alike: nothing was cleared, nothing will be appended)
     if (blockIdx.x == 0 && cnt_next)
         for (int s = threadIdx.x; s < nsplits; s += 64 * WAVES) cnt_next[s] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && work_next) *work_next = 0u;
+    __shared__ unsigned next_chunk;
     __syncthreads();
+#ifdef ICPMI_GROUPS_CLOCKS
+    stamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     const unsigned total = pre[nsplits];
-#pragma unroll 1
-    for (unsigned c = blockIdx.x; c < total; c += gridDim.x) {
+    // chunk c -> its split, and this wave's list entry (requested, not waited for)
+    auto lookup = [&](const unsigned c, int &s, bool &active, unsigned &gv) {
         int slo = 0, shi = nsplits; // pre[slo] <= c < pre[shi]
         while (shi - slo > 1) {
             const int mid = (slo + shi) >> 1;
             if (pre[mid] <= c) slo = mid;
             else shi = mid;
         }
-        const int s = __builtin_amdgcn_readfirstlane(slo);
+        s = __builtin_amdgcn_readfirstlane(slo);
         const unsigned item = (c - pre[s]) * WAVES + (unsigned)wave;
-        const bool active = item < cnt[s];
-        const int g = __builtin_amdgcn_readfirstlane(active ? (int)items[(size_t)s * cap + item] : 0);
+        active = item < lcnt[s];
+        gv = active ? items[(size_t)s * cap + item] : 0u;
+    };
+    unsigned c = blockIdx.x;
+#pragma unroll 1
+    while (c < total) {
+        unsigned gv = 0u;
+        int s = 0;
+        bool active = false;
+        lookup(c, s, active, gv);
+        const int g = __builtin_amdgcn_readfirstlane((int)gv);
+#ifdef ICPMI_GROUPS_CLOCKS
+        if (nchunk < 3) stamp[2 + 2 * nchunk] = __builtin_amdgcn_s_memrealtime();
+        if (nchunk == 0) stamp[8] = (unsigned long long)s | ((unsigned long long)__popcll(__ballot(active)) << 32);
+#endif
         coarse_unit_rows<2, kCoarseQT, WAVES, QSOA>(lds, g * kGroupRows, active, s, nsplits, qry, n, qstride, Bpack, frames, nullptr, nullptr,
                                                     kl);
-        __syncthreads(); // the epilogue's LDS is the next chunk's operand buffer
+        __syncthreads(); // the epilogue's LDS is the next chunk's operand buffer; everybody has read next_chunk
+#ifdef ICPMI_GROUPS_CLOCKS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (nchunk < 3) stamp[3 + 2 * nchunk] = __builtin_amdgcn_s_memrealtime();
+        ++nchunk;
+#endif
+        // the next chunk is claimed only now, when this one is done: a workgroup that claimed ahead would sit on a chunk
+        // while its faster neighbours have run out (the other workgroup of the CU fills the claim's round trip)
+        if (threadIdx.x == 0) next_chunk = gridDim.x + atomicAdd(work, 1u);
+        __syncthreads();
+        c = next_chunk;
     }
+#ifdef ICPMI_GROUPS_CLOCKS
+    if (clocks && threadIdx.x == 0) {
+        stamp[10] = __builtin_amdgcn_s_memrealtime();
+        stamp[11] = (unsigned long long)nchunk;
+        stamp[9] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); // HW_ID | XCC_ID
+        for (int k = 0; k < kGroupStamps; ++k) clocks[(size_t)blockIdx.x * kGroupStamps + k] = stamp[k];
+    }
+#endif
 }
 
 } // namespace icpmi

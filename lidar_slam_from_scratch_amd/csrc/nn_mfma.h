@@ -565,7 +565,11 @@ __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const
                     unsigned mask = 0u;
 #pragma unroll
                     for (int c = 0; c < 16; ++c) mask |= min_raw(v[c] + pnq, kBig) <= thr_q ? (1u << c) : 0u;
+#if defined(ICPMI_TIMING_NO_ATOMIC) /* timing experiment only (WRONG results): what the returning atomic costs */
+                    const int pos = 0;
+#else
                     const int pos = atomicAdd(kl.cnt + iq, 1);
+#endif
                     if (pos < kl.cap) kl.ent[(size_t)iq * kl.cap + pos] = ((unsigned)s << 17) | ((unsigned)half << 16) | mask;
                 }
             }
@@ -690,7 +694,11 @@ __device__ __forceinline__ void coarse_unit_rows(uint4 *lds, const int q0, const
     }
 
     __syncthreads(); // every wave is done with the B operands
+#if defined(ICPMI_TIMING_SKIP_EPILOGUE) /* timing experiment only (WRONG results) */
+    if (active && lane == 99)
+#else
     if (active)
+#endif
         coarse_epilogue<MODE, QT>(reinterpret_cast<float *>(lds) + wave * (32 * 36), lane, q0, s, nsplits, n, m, pn, coarse,
                                   slotmin, kl, thr);
 #ifdef ICPMI_COARSE_CLOCKS
@@ -1033,6 +1041,22 @@ __device__ __forceinline__ void resolve_certify(const float (&pv)[KEEP > 0 ? KEE
 #define ICPMI_RESOLVE_WW 4 /* waves per workgroup = Q * WW queries per partial row of normal-equation terms */
 #endif
 constexpr int kResolveWW = ICPMI_RESOLVE_WW;
+// A second level for the normal-equation sums of the large-cloud resolve kernels (round 4).  Every resolve workgroup
+// leaves one partial row (64 queries); at C3 the kernel that follows -- every one of its ~100 workgroups -- summed 1,563 of
+// them (400 KB through one CU, four rounds of loads: 6.7 of its 17 us), at 1M rows 15,625.  Now the workgroup that is
+// the LAST of its group of kSumGroup consecutive ones to finish adds the group's rows, in index order whoever arrives
+// last, into one row of `rows2`: the step kernels read ceil(nblocks / kSumGroup) rows.  The hand-off is the usual one:
+// every writer fences its row, one thread takes a ticket with an agent-scope atomic, the last arriver fences again and
+// reads the rows past its CU's L1 (agent-scope atomic loads), and puts the ticket back to zero for the next pass.
+// The order of the additions is fixed, so the sums stay run-to-run bit-stable; it is a different order from round 3's
+// (the history's last bits moved once, inside every tolerance of the tests).  rows2 == nullptr: one level, as before
+// (the quarter-wave kernels of the small-cloud regime, whose few hundred rows are one round of loads).
+constexpr int kSumGroup = 16;
+struct SumTree {
+    double *rows2;       // [ceil(nblocks / kSumGroup)][kSumsStride]
+    unsigned *tickets;   // [ceil(nblocks / kSumGroup)], zero between launches
+    int nblocks;         // workgroups (first-level rows) of the launch
+};
 // The end of the Q-queries-per-wave resolve kernels (k_nn_resolve, k_nn_resolve_bounded): results out, counters, and the
 // fused residual + normal-equation terms.  (jspec, q*, n*): the matched target and normal gathered ahead for target
 // `jspec` (< 0: nothing was gathered).
@@ -1044,7 +1068,8 @@ __device__ __forceinline__ void resolve_finish(const int lane, const int wave, c
                                                const unsigned extra_slots, const unsigned extra_splits,
                                                const double *__restrict__ tgt_orig, const double *__restrict__ nrm,
                                                double *__restrict__ partials, const int jspec, double q0, double q1,
-                                               double q2, double n0, double n1, double n2)
+                                               double q2, double n0, double n1, double n2,
+                                               const SumTree tree = SumTree{nullptr, nullptr, 0})
 {
     if (valid && sub == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
@@ -1129,6 +1154,30 @@ __device__ __forceinline__ void resolve_finish(const int lane, const int wave, c
             for (int w = 4; w < kResolveWW; ++w) v += red[w][e];
             partials[(size_t)blockIdx.x * kSumsStride + e] = v;
         }
+        if (tree.rows2) { // (uniform over the launch)
+            __shared__ int last_of_group;
+            __threadfence(); // this thread's part of the row is visible to the whole device ...
+            __syncthreads(); // ... and so is everybody else's, before the ticket is taken
+            const int grp = blockIdx.x / kSumGroup;
+            const int members = tree.nblocks - grp * kSumGroup < kSumGroup ? tree.nblocks - grp * kSumGroup : kSumGroup;
+            if (threadIdx.x == 0) {
+                const unsigned t = __hip_atomic_fetch_add(tree.tickets + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last_of_group = t == (unsigned)(members - 1);
+                if (last_of_group) __hip_atomic_store(tree.tickets + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (last_of_group) {
+                __threadfence();
+                if (threadIdx.x < 28) {
+                    const int e = threadIdx.x;
+                    const double *rows = partials + (size_t)grp * kSumGroup * kSumsStride + e;
+                    double v = __hip_atomic_load(rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int r = 1; r < members; ++r)
+                        v += __hip_atomic_load(rows + (size_t)r * kSumsStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tree.rows2[(size_t)grp * kSumsStride + e] = v;
+                }
+            }
+        }
     }
 }
 
@@ -1181,7 +1230,8 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
                                                     double *__restrict__ partials,
                                                     const int *__restrict__ blk_cnt,
                                                     const int *__restrict__ blk_list,
-                                                    const IcpState *__restrict__ st)
+                                                    const IcpState *__restrict__ st,
+                                                    const SumTree tree = SumTree{nullptr, nullptr, 0})
 {
     static_assert(Q == 16 || Q == 32, "queries per wave");
     constexpr int SUBS = 64 / Q;   // lanes per query
@@ -1296,7 +1346,7 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     resolve_certify<SUBS, Q, KEEP, ICPMI_RESOLVE_SCANBATCH>(pv, lane, sub, valid, ic, n, px, py, pz, coarse, splits, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                              bd, bj, extra_slots, extra_splits);
     resolve_finish<Q>(lane, wave, ql, sub, i, valid, bd, bj, px, py, pz, m, idx, d2out, counters, extra_slots, extra_splits,
-                      tgt_orig, nrm, partials, jspec, q0, q1, q2, n0, n1, n2);
+                      tgt_orig, nrm, partials, jspec, q0, q1, q2, n0, n1, n2, tree);
 }
 
 // The end of the quarter-wave resolve kernels (k_nn_resolve4, k_nn_resolve4_bounded): results out, counters, and the fused

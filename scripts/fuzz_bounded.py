@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the bounded ICP passes (nn_bounded.h) against the unbounded ones (run on the GPU box): the
-same registration with ICPMI_NN_BOUNDED=1 and =0 in one process must give the same bits -- pose, history, iteration
-count -- with the all-pairs engine and with the pruned one, whatever the clouds: sizes on both sides of the two resolve layouts and coarse unit sizes, awkward distributions
+same registration with ICPMI_NN_BOUNDED=1 and =0 on the all-pairs engine, and on the culled engine (bounded passes on
+the (64-row group, split) pairs within reach, nn_culled.h), in one process must give the same bits -- pose, history,
+iteration count -- whatever the clouds: sizes on both sides of the two resolve layouts and coarse unit sizes, awkward distributions
 (clusters, planes, lines, exact ties and duplicates, mixed scales, far offsets), motions from a hair to far outside the
 basin (every row then takes the exhaustive path), NaN / infinite rows.  Any difference is printed with the seed that
 reproduces it; exit code 1 then.
@@ -62,22 +63,28 @@ def main():
         src, tgt, iters, tol, info = make_case(seed)
         n_t = info["n_t"]
         cfg = capi.Context.make_config(iters, tol, 0.0)
-        for engine, ctx in ctxs.items():
-            out = {}
-            for knob in ("1", "0"):
-                os.environ["ICPMI_NN_BOUNDED"] = knob
-                ctx.reset_profile()
-                res, hist = ctx.align(src, tgt, cfg)
-                p = ctx.get_profile()
-                out[knob] = (tuple(res.transformation[:]), tuple(hist), res.num_iterations, bool(res.converged), res.final_error)
-                if knob == "1":
-                    bounded_total += int(p["bounded_launches"]); exhaustive_total += int(p["nn_fallback_queries"])
-            same = all((a == b) or (isinstance(a, float) and a != a and b != b) for a, b in zip(out["1"][2:], out["0"][2:])) and \
-                np.array_equal(np.array(out["1"][0]), np.array(out["0"][0]), equal_nan=True) and \
-                np.array_equal(np.array(out["1"][1]), np.array(out["0"][1]), equal_nan=True)
+        # the reference: the all-pairs engine with every pass unbounded (coarse minima + certificate, round 2's form); against
+        # it, bit for bit, the all-pairs engine's bounded passes and the culled engine (which has bounded passes only; the rows
+        # are in the same Morton order in all three, so the sums are formed in the same order)
+        out = {}
+        for engine, knob in (("all pairs", "0"), ("all pairs", "1"), ("pruned", "1")):
+            ctx = ctxs[engine]
+            os.environ["ICPMI_NN_BOUNDED"] = knob
+            ctx.reset_profile()
+            res, hist = ctx.align(src, tgt, cfg)
+            p = ctx.get_profile()
+            out[(engine, knob)] = (tuple(res.transformation[:]), tuple(hist), res.num_iterations, bool(res.converged), res.final_error)
+            if knob == "1":
+                bounded_total += int(p["bounded_launches"]); exhaustive_total += int(p["nn_fallback_queries"])
+        ref = out[("all pairs", "0")]
+        for key in (("all pairs", "1"), ("pruned", "1")):
+            got = out[key]
+            same = all((a == b) or (isinstance(a, float) and a != a and b != b) for a, b in zip(got[2:], ref[2:])) and \
+                np.array_equal(np.array(got[0]), np.array(ref[0]), equal_nan=True) and \
+                np.array_equal(np.array(got[1]), np.array(ref[1]), equal_nan=True)
             if not same:
                 bad += 1
-                print("MISMATCH seed %d engine %s n_t %d n_s %d iters %d: %s vs %s" % (seed, engine, n_t, src.shape[0], iters, out["1"][1], out["0"][1]))
+                print("MISMATCH seed %d engine %s n_t %d n_s %d iters %d: %s vs %s" % (seed, key[0], n_t, src.shape[0], iters, got[1], ref[1]))
         if (t + 1) % 10 == 0:
             print("%d trials, %d mismatches, %d bounded passes, %d rows searched exhaustively, %.0f s"
                   % (t + 1, bad, bounded_total, exhaustive_total, time.time() - t0), flush=True)

@@ -35,6 +35,8 @@ def main():
             "mfma": capi.Context(device=0, search=capi.SEARCH_MFMA_BF16), "pruned": capi.Context(device=0, search=capi.SEARCH_MFMA_PRUNED)}
     kinds = ["uniform", "clusters", "plane", "line", "grid", "mixed"]
     bad = 0
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    stop_stats = {"decided": 0, "under": 0, "exhausted": 0, "min_margin": float("inf")}
     t0 = time.time()
     for t in range(trials):
         seed = seed0 + t
@@ -117,9 +119,16 @@ def main():
                         or not np.allclose(hist, ref.error_history, rtol=1e-4, atol=1e-6 * scale) or dt > 1e-4 * scale or dr > 1e-4):
                     bad += 1
                     print("MISMATCH align seed %d engine %s kind %s n_t %d: %s vs %s" % (seed, name, tkind, n_t, hist, ref.error_history))
+        # the stopping tests with the caller's settings (50, 1e-6, 1e-9) on well-conditioned pairs: iteration count,
+        # flag and history length equal to the oracle's wherever the margin allows (scripts/fuzz_stopping.py), every
+        # eighth trial (a registration to convergence costs what a dozen of the legs above do)
+        if t % 8 == 7:
+            import fuzz_stopping
+            bad += fuzz_stopping.check_case(seed, {k: ctxs[k] for k in ("auto", "mfma", "pruned")}, fuzz_stopping.caller_config(), stop_stats)
         if (t + 1) % 20 == 0:
             print("%d trials, %d mismatches, %.0f s" % (t + 1, bad, time.time() - t0), flush=True)
-    print("fuzz: %d trials, %d mismatches" % (trials, bad))
+    print("fuzz: %d trials, %d mismatches; stopping tests: %d registrations decided (smallest margin %.3g), %d under the 1e-12 floor"
+          % (trials, bad, stop_stats["decided"], stop_stats["min_margin"], stop_stats["under"]))
     return 1 if bad else 0
 
 if __name__ == "__main__":

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""The stopping tests of the ICP loop (icp.hpp:210-217), fuzzed on the GPU against the oracle loop (run on the GPU box).
+
+"Same iteration count" is the north_star's own gate, and it is decided by `error < min_error` and
+`|prev_error - error| < tolerance` on an error whose last bits depend on the order of the additions.  Every trial is a
+registration with the CALLER's settings (slam_node.cpp:134-138: 50 iterations, tolerance 1e-6, min_error 1e-9) on
+well-conditioned geometry -- LiDAR-like frame pairs of the synthetic street at random frames, beam counts and voxel
+sizes, and room corners (three planes) with random motions and noise -- through every MFMA engine (all pairs, culled,
+AUTO) and compared with the oracle's loop:
+
+    num_iterations, converged, history length        must be EQUAL
+
+on every trial whose MARGIN exceeds 1e-12, where margin = the smallest distance of any stopping test the oracle evaluated
+from flipping, min over the loop's iterations of | |prev - err| - tolerance | and | err - min_error |
+(scripts/iteration_sensitivity.py's measure, here taken from the oracle's own error history: the tests are functions of
+consecutive entries).  Trials under that margin are COUNTED and printed, not skipped silently: there an equal count is
+luck on both sides.  Pose and history are also held to the north_star's tolerances.
+usage: python scripts/fuzz_stopping.py [trials] [first_seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # noqa: F401
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lidar_slam_from_scratch_amd import capi, synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+MAX_IT, TOL, MIN_ERR = 50, 1e-6, 1e-9      # slam_node.cpp:134-138
+MARGIN_FLOOR = 1e-12
+
+
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    if rng.random() < 0.6:
+        # a frame pair of the synthetic street: frames a few steps apart, random resolution and voxel size
+        f0 = int(rng.integers(0, 150))
+        gap = int(rng.choice([1, 1, 2, 3]))
+        beams = int(rng.choice([16, 32, 64]))
+        az = int(rng.choice([450, 900, 1800]))
+        voxel = float(rng.choice([0.3, 0.5, 0.8]))
+        tgt = synth.lidar_frame(f0, voxel=voxel, beams=beams, azimuths=az)
+        src = synth.lidar_frame(f0 + gap, voxel=voxel, beams=beams, azimuths=az)
+        return src, tgt, "lidar f%d+%d b%d az%d v%.1f" % (f0, gap, beams, az, voxel)
+    # a room corner: three orthogonal planes, source an independent noisy sample moved by a small rigid motion
+    n_t = int(rng.choice([3000, 8000, 20000, 45000, 70000]))
+    n_s = int(rng.choice([2000, 5000, 12000, 40000]))
+    noise = float(rng.choice([0.002, 0.005, 0.02]))
+    ext = float(rng.choice([10.0, 20.0, 40.0]))
+    tgt = synth._room_corner(n_t, seed * 2 + 1, noise=noise, extent=ext)
+    src0 = synth._room_corner(n_s, seed * 2 + 2, noise=noise, extent=ext)
+    T = synth.make_transform(rng.normal(0, 0.015, 3), rng.normal(0, 0.08, 3))
+    src = np.ascontiguousarray(synth.apply_transform(synth.invert_transform(T), src0))
+    return src, tgt, "corner %d->%d noise %g ext %g" % (n_s, n_t, noise, ext)
+
+
+def oracle_margin(ref):
+    """Distance of the nearest evaluated stopping test from flipping, from the oracle's own history.  The history is
+    e_0 .. e_k of the loop, then the post-loop entry (icp.hpp:235-252)."""
+    h = np.asarray(ref.error_history, dtype=np.float64)
+    loop = h[:-1]
+    m = np.inf
+    prev = np.finfo(np.float64).max
+    for e in loop:
+        m = min(m, abs(abs(prev - e) - TOL), abs(e - MIN_ERR))
+        prev = e
+    return float(m)
+
+
+def check_case(seed, ctxs, cfg, stats):
+    """One trial through every context of `ctxs` -> mismatches; `stats` (decided / under / exhausted / min_margin) is updated."""
+    src, tgt, what = make_case(seed)
+    ref = orc.icp_point_to_plane(src, tgt, MAX_IT, TOL, MIN_ERR, nthreads=os.cpu_count() or 1)
+    margin = oracle_margin(ref)
+    bad = 0
+    if not ref.converged:
+        stats["exhausted"] += 1
+    if margin <= MARGIN_FLOOR:
+        stats["under"] += 1
+        print("UNDER MARGIN seed %d (%s): margin %.3g -- counts compared below are not held against the run" % (seed, what, margin))
+    else:
+        stats["decided"] += 1
+        stats["min_margin"] = min(stats["min_margin"], margin)
+    for name, ctx in ctxs.items():
+        res, hist = ctx.align(src, tgt, cfg)
+        Tg = np.array(res.transformation[:]).reshape(4, 4)
+        dt, dr = synth.pose_delta(Tg, ref.transformation)
+        same = (res.num_iterations == ref.num_iterations and bool(res.converged) == bool(ref.converged)
+                and len(hist) == len(ref.error_history))
+        if margin > MARGIN_FLOOR and not same:
+            bad += 1
+            print("MISMATCH stopping seed %d (%s) engine %s: iterations %d vs %d, converged %s vs %s, history %d vs %d, margin %.3g"
+                  % (seed, what, name, res.num_iterations, ref.num_iterations, bool(res.converged), ref.converged, len(hist),
+                     len(ref.error_history), margin))
+        elif same and (dt > 1e-4 or dr > 1e-4 or not np.allclose(hist, ref.error_history, rtol=0, atol=1e-9)):
+            bad += 1
+            print("MISMATCH stopping seed %d (%s) engine %s: pose %.3g m %.3g rad, history diff %.3g"
+                  % (seed, what, name, dt, dr, float(np.abs(np.asarray(hist) - np.asarray(ref.error_history)).max())))
+    return bad
+
+
+def new_stats():
+    return {"decided": 0, "under": 0, "exhausted": 0, "min_margin": np.inf}
+
+
+def caller_config():
+    return capi.Context.make_config(max_iterations=MAX_IT, tolerance=TOL, min_error=MIN_ERR)
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    trials = int(argv[1]) if len(argv) > 1 else 40
+    seed0 = int(argv[2]) if len(argv) > 2 else 9000
+    engines = {"auto": capi.SEARCH_AUTO, "all pairs": capi.SEARCH_MFMA_BF16, "culled": capi.SEARCH_MFMA_PRUNED}
+    ctxs = {k: capi.Context(device=0, search=v) for k, v in engines.items()}
+    cfg = caller_config()
+    bad, stats = 0, new_stats()
+    t0 = time.time()
+    for t in range(trials):
+        bad += check_case(seed0 + t, ctxs, cfg, stats)
+        if (t + 1) % 10 == 0:
+            print("%d trials, %d mismatches, %d under the margin floor, %.0f s" % (t + 1, bad, stats["under"], time.time() - t0), flush=True)
+    print("fuzz_stopping: %d trials x %d engines, %d mismatches; %d trials decided (smallest margin %.3g), %d under the 1e-12 floor, "
+          "%d ran out of iterations in the oracle" % (trials, len(ctxs), bad, stats["decided"], stats["min_margin"], stats["under"],
+                                                      stats["exhausted"]))
+    for c in ctxs.values():
+        c.close()
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
