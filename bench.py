@@ -336,11 +336,11 @@ def main():
         if not prof["coarse_launches"] or not prof["bounded_launches"]:
             return None
         k_ms = prof["coarse_ms"] / prof["coarse_launches"]
-        pairs_run = prof["nn_group_pairs_run"] * 64.0 * 2048.0 / max(1, prof["bounded_launches"])   # per launch
+        pairs_run = prof["nn_group_pairs_run"] * 32.0 * 2048.0 / max(1, prof["bounded_launches"])   # per launch (32-row tile x 2048-target split)
         pairs_all = float(n_local) * float(m)
         ach = FLOP_PER_PAIR * pairs_run / (k_ms * 1e-3) / 1e12
-        return {"kernel": "k_nn_coarse_groups (bf16 MFMA over the (64-row group, 2048-target split) pairs whose boxes are "
-                          "within the group's bound of each other)",
+        return {"kernel": "k_nn_coarse_groups (bf16 MFMA over the (32-row tile, 2048-target split) pairs whose boxes are "
+                          "within the tile's bound of each other)",
                 "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                 "traffic": None, "avg_launch_ms": k_ms, "launches_timed": int(prof["coarse_launches"]),
                 "executed_pairs_per_launch": pairs_run, "all_pairs_per_launch": pairs_all,
@@ -388,7 +388,7 @@ def main():
                 "history_bit_equal": bool(np.array_equal(np.asarray(dhist), np.asarray(hist))),
                 "comm": comm_block(dprof),
                 "note": "same correspondences as the all-pairs pass (the reference's own search culls too: kdtree.hpp:139,177); "
-                        "(row group, split) pairs culled by a bounding-box test against each row's bound -- the previous "
+                        "(32-row tile, split) pairs culled by a bounding-box test against each row's bound -- the previous "
                         "match's exact distance, in a call's first pass the nearest sorted target around the row's Morton place"}
         except Exception as e:  # noqa: BLE001  (the headline must not depend on the second series)
             default_engine = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -53,8 +53,8 @@ extern "C" {
 #define ICPMI_SEARCH_AUTO 0
 #define ICPMI_SEARCH_EXACT_F64 1     /* fp64 brute force, SGPR-broadcast targets */
 #define ICPMI_SEARCH_MFMA_BF16 2     /* bf16 MFMA coarse pass over ALL pairs + certified fp64 resolve */
-#define ICPMI_SEARCH_MFMA_PRUNED 3   /* the same, skipping (64-row group, target split) pairs whose bounding
-                                        boxes are farther apart than the group's known neighbour distance -- the
+#define ICPMI_SEARCH_MFMA_PRUNED 3   /* the same, skipping (32-row tile, target split) pairs whose bounding
+                                        boxes are farther apart than the tile's known neighbour distance -- the
                                         rule of kdtree.hpp:139,177 applied to groups; same exact result, not an
                                         all-pairs pass (registrations and normal estimation).  AUTO takes it for
                                         targets of more than 16 splits (32,768 points), engine 2 below that */
@@ -107,7 +107,7 @@ typedef struct {
     int64_t nn_pruned_blocks;                        /* of those, skipped by ICPMI_SEARCH_MFMA_PRUNED's box test */
     int64_t small_launches;                          /* iterations run by the small-cloud kernel (search + residuals + pose update in one launch) */
     int64_t bounded_launches;                        /* passes of the ICP loop searched behind a bound per row (lists instead of coarse minima) */
-    int64_t nn_group_pairs;                          /* culled engine: (64-row group, 2048-target split) pairs of its passes ... */
+    int64_t nn_group_pairs;                          /* culled engine: (32-row tile, 2048-target split) pairs of its passes ... */
     int64_t nn_group_pairs_run;                      /* ... and those within reach, the ones the coarse pass evaluated */
     double exchange_ms;  int64_t exchange_launches;  /* sharded runs: the per-pass all-reduce of 30 doubles alone (the launches bracketed) */
 } icpmi_profile;

@@ -227,9 +227,6 @@ struct icpmi_ctx {
     int nn_splits = 0;
     int nn_ms = 0;                            // component stride of the SoA sorted target
     int grp_cap = 0;                          // groups a split's list in grp_items can hold
-    bool tickets_clean = false;               // the sum tree's tickets (ctx->partials) are known to be zero
-    const void *tickets_at = nullptr;         // ... where they were last
-    int tickets_n = 0;
     IcpState *d_state = nullptr;   // two of them (align_device alternates in the sharded loop)
     IcpState *h_state = nullptr;   // pinned
     double *h_hist = nullptr;      // pinned: the error history of the last call
@@ -629,8 +626,9 @@ int reserve_group_lists(icpmi_ctx *ctx, int splits, long groups)
     int rc;
     const size_t per = ((size_t)splits + kGrpCntPad - 1) / kGrpCntPad * kGrpCntPad;
     if ((rc = reserve(ctx, ctx->grp_cnt, sizeof(unsigned) * 2 * per + 2 * sizeof(unsigned long long) + 4 * sizeof(unsigned)))) return rc;
-    if ((rc = reserve(ctx, ctx->grp_items, sizeof(unsigned) * (size_t)splits * (size_t)std::max<long>(groups, 1)))) return rc;
-    ctx->grp_cap = (int)std::max<long>(groups, 1);
+    const long cap = (std::max<long>(groups, 1) + 1) / 2 * 2; // (even: the coarse kernel reads a wave's two entries as one 8-byte word)
+    if ((rc = reserve(ctx, ctx->grp_items, sizeof(unsigned) * (size_t)splits * (size_t)cap + 16))) return rc;
+    ctx->grp_cap = (int)cap;
     return ICPMI_OK;
 }
 GroupLists group_lists(const icpmi_ctx *ctx, int set)
@@ -691,8 +689,7 @@ unsigned long long *groups_clock_buffer(icpmi_ctx *ctx)
 // in ctx->nn_lists (RowBounds, kernels.h; nn_bounded.h)
 int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx, double *d_d2,
                    const IcpState *st, const double *d_tgt = nullptr, const double *d_nrm = nullptr,
-                   double *d_partials = nullptr, int pruned_pass = -1, bool bounded = false,
-                   const SumTree tree = SumTree{nullptr, nullptr, 0})
+                   double *d_partials = nullptr, int pruned_pass = -1, bool bounded = false)
 {
     const int splits = ctx->nn_splits;
     int rc;
@@ -743,7 +740,7 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, splits, frames, (const double *)ub_row, (const int *)cnt_row, \
         (const unsigned *)ent_row, d_idx, ctx->opt.profile >= 2 ? counters : (unsigned long long *)nullptr, d_tgt, d_nrm, d_partials, st
         switch (resolve_waves(n)) {
-        case 0: hipLaunchKernelGGL(k_nn_resolve_bounded, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_BOUNDED_ARGS, tree); break;
+        case 0: hipLaunchKernelGGL(k_nn_resolve_bounded, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
         case 4: hipLaunchKernelGGL(k_nn_resolve4_bounded<4>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
         case 8: hipLaunchKernelGGL(k_nn_resolve4_bounded<8>, dim3(resolve_blocks(n)), dim3(512), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
         default: hipLaunchKernelGGL(k_nn_resolve4_bounded<16>, dim3(resolve_blocks(n)), dim3(1024), 0, ctx->stream, ICPMI_BOUNDED_ARGS); break;
@@ -775,8 +772,8 @@ int launch_nn_mfma(icpmi_ctx *ctx, const double *d_qry, int n, int m, int *d_idx
     d_qry, n, (const double *)ctx->tgt_sorted.p, perm, m, ctx->nn_ms, (const float2 *)ctx->coarse.p, splits, frames,  \
         (const NnFrame *)ctx->nn_misc.p, d_idx, d_d2, counters, d_tgt, d_nrm, d_partials, blk_cnt, blk_list, st
     switch (resolve_waves(n)) {
-    case 0: hipLaunchKernelGGL(k_nn_resolve<16>, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_RESOLVE_ARGS, tree); break;
-    case -32: hipLaunchKernelGGL(k_nn_resolve<32>, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_RESOLVE_ARGS, tree); break;
+    case 0: hipLaunchKernelGGL(k_nn_resolve<16>, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
+    case -32: hipLaunchKernelGGL(k_nn_resolve<32>, dim3(resolve_blocks(n)), dim3(64 * kResolveWW), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     case 4: hipLaunchKernelGGL(k_nn_resolve4<4>, dim3(resolve_blocks(n)), dim3(256), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     case 8: hipLaunchKernelGGL(k_nn_resolve4<8>, dim3(resolve_blocks(n)), dim3(512), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
     default: hipLaunchKernelGGL(k_nn_resolve4<16>, dim3(resolve_blocks(n)), dim3(1024), 0, ctx->stream, ICPMI_RESOLVE_ARGS); break;
@@ -903,11 +900,11 @@ int launch_knn(icpmi_ctx *ctx, const double *d_qry, int nq_total, const double *
                 hipLaunchKernelGGL(k_knn_prebound, dim3((nq + kPreRows - 1) / kPreRows), dim3(256), 0, s, sorted, m, ctx->nn_ms, k, (int)c0, nq,
                                    t_row, tf_row, sqf_row, cnt_row);
                 if (lists_culled) {
-                    // the groups are runs of 64 sorted rows, their bound the largest of their rows' (nn_culled.h)
+                    // the groups are runs of 32 sorted rows, their bound the largest of their rows' (nn_culled.h); a wave takes two
                     const GroupLists gl = group_lists(ctx, 0);
-                    const int groups = (nq + kGroupRows - 1) / kGroupRows;
+                    const int waves = (nq + 63) / 64;
                     HIP_TRY(ctx, hipMemsetAsync(ctx->grp_cnt.p, 0, group_cnt_bytes(ctx), s));
-                    hipLaunchKernelGGL(k_knn_group_cull, dim3((groups + 15) / 16), dim3(1024), 0, s, sorted, m, ctx->nn_ms, (int)c0, nq,
+                    hipLaunchKernelGGL(k_knn_group_cull, dim3((waves + 15) / 16), dim3(1024), 0, s, sorted, m, ctx->nn_ms, (int)c0, nq,
                                        (const double *)t_row, frames, splits, gl);
 #define ICPMI_GROUPS_ARGS                                                                                                                   \
     sorted + c0, nq, (size_t)ctx->nn_ms, (const uint4 *)ctx->bpack.p, frames, splits, (const unsigned *)gl.items, gl.cap,                  \
@@ -1200,35 +1197,21 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // small clouds: one kernel per iteration for the rows' work (icp_small.h), then k_finish_step
     const bool small = !sharded_run && n > 0 && n <= small_max_queries() && small_target(ctx);
     const int rblocks = small ? (n + kSmallQ - 1) / kSmallQ : (fused ? resolve_blocks(n) : reduce_blocks(ctx, n));
-    // the large-cloud resolve kernels add their partial rows up in groups of kSumGroup (SumTree, nn_mfma.h): the step kernels
-    // then sum rblocks2 rows (ICPMI_SUM_TREE=0: one level, round 3's order of additions -- the A/B knob)
-    static const bool sum_tree_on = [] {
-        const char *e = getenv("ICPMI_SUM_TREE");
-        return !(e && e[0] == '0' && e[1] == '\0');
+    // very many partial rows (a resolve workgroup leaves one per 64 queries) are first added in groups of kSumGroup by a
+    // kernel of their own (k_sum_groups, kernels.h): the step kernels then sum rblocks2 rows
+    static const int sum_tree_from = [] {
+        if (const char *e = getenv("ICPMI_SUM_TREE_FROM")) {
+            const long x = strtol(e, nullptr, 10);
+            if (x >= 1) return (int)std::min<long>(x, 2000000000l);
+        }
+        return kSumTreeFrom;
     }();
-    const bool sum_tree = sum_tree_on && fused && !small && n > 0 && resolve_waves(n) <= 0;
+    const bool sum_tree = rblocks >= sum_tree_from;
     const int rblocks2 = sum_tree ? (rblocks + kSumGroup - 1) / kSumGroup : 0;
-    {
-        const size_t cap_before = ctx->partials.cap;
-        if ((rc = reserve(ctx, ctx->partials, sizeof(double) * kSumsStride * ((size_t)rblocks + (size_t)rblocks2) + sizeof(unsigned) * (size_t)rblocks2 + 64))) return rc;
-        if (ctx->partials.cap != cap_before) ctx->tickets_clean = false;
-    }
+    if ((rc = reserve(ctx, ctx->partials, sizeof(double) * kSumsStride * ((size_t)rblocks + (size_t)rblocks2)))) return rc;
     double *partials = (double *)ctx->partials.p;
-    SumTree tree{nullptr, nullptr, 0};
-    if (sum_tree) {
-        tree = SumTree{partials + kSumsStride * (size_t)rblocks, (unsigned *)(partials + kSumsStride * ((size_t)rblocks + (size_t)rblocks2)), rblocks};
-        // the tickets are back at zero after every completed launch; a buffer fresh from the allocator, one last used with
-        // another layout, or a call that did not finish leaves them unknown
-        if (!ctx->tickets_clean || ctx->tickets_at != (const void *)tree.tickets || ctx->tickets_n != rblocks2)
-            HIP_TRY(ctx, hipMemsetAsync(tree.tickets, 0, sizeof(unsigned) * (size_t)rblocks2, s));
-        ctx->tickets_at = tree.tickets;
-        ctx->tickets_n = rblocks2;
-        ctx->tickets_clean = false; // (until this call has come back)
-    }
-    else
-        ctx->tickets_clean = false; // (this call's rows may lie where another layout kept its tickets)
-    // what the step kernels sum: the second-level rows where there are any
-    const double *fin_rows = sum_tree ? tree.rows2 : partials;
+    // what the step kernels sum
+    const double *fin_rows = sum_tree ? partials + kSumsStride * (size_t)rblocks : partials;
     const int fin_blocks = sum_tree ? rblocks2 : rblocks;
 
     // normals of the target (icp.hpp:169-171).  With several ranks each computes a slice of
@@ -1365,8 +1348,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         const bool fuse_finish = !sharded && n > 0 && !final_pass && fuse_finish_enabled();
         if (n > 0 && fused) {
             if ((r2 = launch_nn_mfma(ctx, cur, n, m, idx, nullptr, st, d_tgt, nrm, partials,
-                                     pruned ? pass_no : -1, bounded_loop /* incumbents in idx, bounds in place: from k_nn_prebound1 or the kernel that moved the rows */,
-                                     tree))) return r2;
+                                     pruned ? pass_no : -1, bounded_loop /* incumbents in idx, bounds in place: from k_nn_prebound1 or the kernel that moved the rows */))) return r2;
             ++pass_no;
         } else if (n > 0) {
             if ((r2 = launch_nn(ctx, cur, n, d_tgt, m, idx, nullptr, st))) return r2;
@@ -1377,6 +1359,9 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
             if (!fused)
                 hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, cur, n, d_tgt, m, nrm, idx, partials,
                                    st);
+            if (sum_tree)
+                hipLaunchKernelGGL(k_sum_groups, dim3((rblocks2 + 7) / 8), dim3(256), 0, s, (const double *)partials, rblocks,
+                                   partials + kSumsStride * (size_t)rblocks, (const IcpState *)st);
             if (sharded) {
                 hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), 0, s, fin_rows, fin_blocks, n,
                                    st);
@@ -1521,14 +1506,13 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         ctx->prof.nn_group_pairs_run += (int64_t)ctx->h_cnt[3];
         ctx->prof.nn_group_pairs += (int64_t)ctx->h_cnt[4];
         // (the older pair of fields, in 512-row units like the all-pairs engine's)
-        ctx->prof.nn_pruned_blocks += (int64_t)(ctx->h_cnt[4] - ctx->h_cnt[3]) / (kCoarseQueries / kGroupRows);
+        ctx->prof.nn_pruned_blocks += (int64_t)(ctx->h_cnt[4] - ctx->h_cnt[3]) / (kCoarseQueries / kGroupRows); // (16 tiles to a 512-row block)
     }
     if (ctx->ev_used > 4096) harvest_profile(ctx); // (otherwise when the profile is asked for)
     if (hs->error)
         return fail(ctx, ICPMI_ERR_RCCL, "the ranks of this sharded run disagreed on the end of the loop "
                                          "(different icpmi_config per rank, or an exchange that is not bit-identical on every rank)");
 
-    ctx->tickets_clean = true; // (every queued resolve launch has completed: its groups' tickets are back at zero)
     memcpy(result->transformation, hs->total, sizeof(double) * 16); // icp.hpp:254
     result->converged = hs->converged;
     result->num_iterations = hs->hist_len - 1;                      // icp.hpp:255
@@ -2072,7 +2056,6 @@ int icpmi_solve_point_to_plane(icpmi_ctx *ctx, const double *source_xyz, const d
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(IcpState), s));
     {
         StageTimer t(ctx, ST_REDUCE);
-        ctx->tickets_clean = false; // (the rows below may lie where a registration's sum tree kept its tickets)
         hipLaunchKernelGGL(k_reduce, dim3(rblocks), dim3(256), 0, s, (const double *)ctx->stage_a.p, n,
                            (const double *)ctx->stage_b.p, n, (const double *)ctx->stage_c.p,
                            (const int *)nullptr, (double *)ctx->partials.p, (const IcpState *)nullptr);

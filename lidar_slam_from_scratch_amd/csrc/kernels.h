@@ -235,6 +235,34 @@ __device__ inline void finish_sums(const double *__restrict__ partials, int nblo
     if (threadIdx.x == 0) st->sums[28] = (double)n_local;
 }
 
+// A second level for the sums of very many partial rows (round 4): a resolve workgroup leaves one row per 64 queries --
+// 15,625 at 1M rows -- and every workgroup of the step kernel summed them all (4 MB through each of its CUs).  From
+// kSumTreeFrom rows on, this small kernel first adds the rows in groups of kSumGroup, in index order: the step kernels sum
+// ceil(nblocks / kSumGroup) rows.  A kernel of its own, not a hand-off inside the resolve kernel: with the last workgroup
+// of a group adding the group's rows behind agent-scope fences the resolve took 170 us instead of 27 at C3 (a release
+// writes the XCD's L2 back, an acquire drops the CU's L1, once per workgroup and seven workgroups to a CU), and the
+// fence-free sc1 form is measured for one workgroup per CU only (MI355X_MICROARCH.md).  A launch boundary costs ~3 us: it
+// pays from a few thousand rows, not at C3's 1,563 (ICPMI_SUM_TREE_FROM moves the threshold; the sums' order of
+// additions differs on either side of it, inside every tolerance of the tests).
+constexpr int kSumGroup = 16;
+constexpr int kSumTreeFrom = 4096;
+__global__ __launch_bounds__(256) void k_sum_groups(const double *__restrict__ rows, int nblocks, double *__restrict__ rows2,
+                                                    const IcpState *__restrict__ st)
+{
+    if (st && st->done) return;
+    const int e = threadIdx.x & 31, grp = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int r0 = grp * kSumGroup;
+    if (r0 >= nblocks || e >= kNumSums) return;
+    const int members = nblocks - r0 < kSumGroup ? nblocks - r0 : kSumGroup;
+    double v[kSumGroup];
+#pragma unroll
+    for (int r = 0; r < kSumGroup; ++r) v[r] = r < members ? rows[(size_t)(r0 + r) * kSumsStride + e] : 0.0; // (all in flight)
+    double s = v[0];
+#pragma unroll
+    for (int r = 1; r < kSumGroup; ++r) s += v[r];
+    rows2[(size_t)grp * kSumsStride + e] = s;
+}
+
 // error, convergence tests, solve, accumulate (icp.hpp:206-231 / 251-255)
 __device__ inline void step_update(IcpState *st, double *history, int final_pass)
 {

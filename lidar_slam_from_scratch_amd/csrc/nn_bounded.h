@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     int splits, const SplitFrame *__restrict__ frames, const double *__restrict__ ub_row, const int *__restrict__ cnt_row,
     const unsigned *__restrict__ ent_row, int *__restrict__ idx /* in: previous match, out: this pass's */,
     unsigned long long *__restrict__ counters, const double *__restrict__ tgt_orig, const double *__restrict__ nrm,
-    double *__restrict__ partials, const IcpState *__restrict__ st, const SumTree tree = SumTree{nullptr, nullptr, 0})
+    double *__restrict__ partials, const IcpState *__restrict__ st)
 {
     constexpr int Q = 16, ROUNDS = Q / 4;
     static_assert(kNnEntCap == 8, "two words per sub-lane");
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
 #endif
     const unsigned extra_slots = (sub == 0 && look && !over && nsl > 1) ? (unsigned)(nsl - 1) : 0u;
     resolve_finish<Q>(lane, wave, ql, sub, i, valid, bd, bj, px, py, pz, m, idx, nullptr, counters, extra_slots, extra_splits,
-                      tgt_orig, nrm, partials, -1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, tree);
+                      tgt_orig, nrm, partials, -1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);
 }
 
 // One query per QUARTER-wave: the lane layout, workgroup shape and sums of k_nn_resolve4<WAVES> (sources of at most

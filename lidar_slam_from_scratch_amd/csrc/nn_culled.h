@@ -29,10 +29,10 @@
 
 namespace icpmi {
 
-constexpr int kGroupRows = 64;          // rows per group: one wave's two 32-row MFMA tiles
+constexpr int kGroupRows = 32;          // rows per group: one 32-row MFMA tile (a wave of the coarse pass takes two, any two of a split's list)
 constexpr int kGroupStamps = 12;        // diagnostic build (-DICPMI_GROUPS_CLOCKS): words per workgroup of k_nn_coarse_groups
 constexpr int kCullMaxSplits = 4096;    // splits whose chunk prefix fits the coarse kernel's LDS (8.4M targets); beyond: all pairs
-static_assert(kGroupRows == kTile * kCoarseQT, "a group is what one wave of the coarse unit takes");
+static_assert(kGroupRows == kTile && kCoarseQT == 2, "a group is one tile; a wave of the coarse unit takes two");
 
 // One list of row groups per target split (the pairs that survived the box test), for the coming coarse pass.
 struct GroupLists {
@@ -54,14 +54,16 @@ struct GroupLists {
 struct CullLds {
     unsigned cnt[kCullMaxSplits];   // survivors of this workgroup per split, then the cursor inside its run
 };
-__device__ __forceinline__ void block_cull(CullLds &lds, const int g, double (&lo)[3], double (&hi)[3], double ub,
+// `g2` = the wave's first tile (its 64 rows are tiles g2 and g2 + 1: lanes 0-31 and 32-63).
+__device__ __forceinline__ void block_cull(CullLds &lds, const int g2, double (&lo)[3], double (&hi)[3], double ub,
                                            const SplitFrame *__restrict__ frames, const int nsplits, const GroupLists &gl,
                                            const int lane)
 {
     __syncthreads(); // (a workgroup with several rounds of rows: the previous round's cursors are no longer in use)
     for (int s = threadIdx.x; s < nsplits; s += blockDim.x) lds.cnt[s] = 0u;
+    // box and bound of each HALF of the wave (one tile each): five exchange steps inside the halves
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 16; off > 0; off >>= 1) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const double l2 = __shfl_xor(lo[a], off, 64), h2 = __shfl_xor(hi[a], off, 64);
@@ -71,10 +73,10 @@ __device__ __forceinline__ void block_cull(CullLds &lds, const int g, double (&l
         const double u2 = __shfl_xor(ub, off, 64);
         ub = u2 > ub ? u2 : ub;
     }
-    const bool any = lo[0] <= hi[0]; // a finite row in the group
-    if (any && !(ub < 1.0e300)) {
+    const bool any = lo[0] <= hi[0]; // a finite row in this half's tile
+    if (__ballot(any && !(ub < 1.0e300)) != 0ull) { // (rare: a tile without any bound)
         double far2 = __builtin_inf();
-        for (int s = lane; s < nsplits; s += 64) {
+        for (int s = lane & 31; s < nsplits; s += 32) {
             double f2 = 0.0;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -85,35 +87,58 @@ __device__ __forceinline__ void block_cull(CullLds &lds, const int g, double (&l
             far2 = f2 < far2 ? f2 : far2;
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+        for (int off = 16; off > 0; off >>= 1) {
             const double o = __shfl_xor(far2, off, 64);
             far2 = o < far2 ? o : far2;
         }
-        ub = far2 * (1.0 + 1e-12);
+        if (!(ub < 1.0e300)) ub = far2 * (1.0 + 1e-12);
     }
-    auto reach = [&](const int s) -> bool {
-        double g2 = 0.0;
+    // every lane gets both tiles' boxes: A = lanes 0-31's, B = lanes 32-63's
+    double alo[3], ahi[3], blo[3], bhi[3], aub, bub;
+    bool aany, bany;
+    {
+        const bool upper = lane >= 32;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double g1 = lo[a] - frames[s].hi[a], g3 = frames[s].lo[a] - hi[a];
-            const double gg = g1 > g3 ? g1 : g3;
-            g2 += gg > 0.0 ? gg * gg : 0.0;
+            const double ol = __shfl_xor(lo[a], 32, 64), oh = __shfl_xor(hi[a], 32, 64);
+            alo[a] = upper ? ol : lo[a], ahi[a] = upper ? oh : hi[a];
+            blo[a] = upper ? lo[a] : ol, bhi[a] = upper ? hi[a] : oh;
         }
-        return !(g2 * (1.0 - 1e-12) > ub * (1.0 + 1e-12));
+        const double ou = __shfl_xor(ub, 32, 64);
+        aub = upper ? ou : ub, bub = upper ? ub : ou;
+        const int oany = __shfl_xor((int)any, 32, 64);
+        aany = upper ? (oany != 0) : any, bany = upper ? any : (oany != 0);
+    }
+    auto reach = [&](const int s, const double (&l)[3], const double (&h)[3], const double u) -> bool {
+        double g2s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double g1 = l[a] - frames[s].hi[a], g3 = frames[s].lo[a] - h[a];
+            const double gg = g1 > g3 ? g1 : g3;
+            g2s += gg > 0.0 ? gg * gg : 0.0;
+        }
+        return !(g2s * (1.0 - 1e-12) > u * (1.0 + 1e-12));
     };
     __syncthreads(); // counters cleared
-    if (any)
-        for (int s = lane; s < nsplits; s += 64)
-            if (reach(s)) atomicAdd(&lds.cnt[s], 1u);
+    for (int s = lane; s < nsplits; s += 64) {
+        const unsigned c = (unsigned)(aany && reach(s, alo, ahi, aub)) + (unsigned)(bany && reach(s, blo, bhi, bub));
+        if (c) atomicAdd(&lds.cnt[s], c);
+    }
     __syncthreads(); // counted
     for (int s = threadIdx.x; s < nsplits; s += blockDim.x) {
         const unsigned c = lds.cnt[s];
         if (c) lds.cnt[s] = atomicAdd(gl.cnt + s, c); // the run [base, base + c) of split s's list is this workgroup's
     }
     __syncthreads(); // runs reserved: cnt[] now holds each run's cursor
-    if (any)
-        for (int s = lane; s < nsplits; s += 64)
-            if (reach(s)) gl.items[(size_t)s * gl.cap + atomicAdd(&lds.cnt[s], 1u)] = (unsigned)g;
+    for (int s = lane; s < nsplits; s += 64) {
+        const bool ra = aany && reach(s, alo, ahi, aub), rb = bany && reach(s, blo, bhi, bub);
+        if (ra || rb) {
+            const unsigned pos = atomicAdd(&lds.cnt[s], (unsigned)ra + (unsigned)rb);
+            unsigned *dst = gl.items + (size_t)s * gl.cap + pos;
+            if (ra) dst[0] = (unsigned)g2;
+            if (rb) dst[ra ? 1 : 0] = (unsigned)g2 + 1u;
+        }
+    }
 }
 
 // What a kernel that moves rows leaves for the bounded pass that follows (RowBatch::finish's images, kernels.h), for one
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(kPreThreads) void k_nn_prebound1(const double *__re
     const int bjc = have ? bj : 0;
     row_bound_store(rb, i, valid, px, py, pz, have, ICPMI_SX(sorted, ms, bjc), ICPMI_SY(sorted, ms, bjc), ICPMI_SZ(sorted, ms, bjc), lo, hi,
                     ubg);
-    if (gl.cnt) block_cull(cl, i / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
+    if (gl.cnt) block_cull(cl, (i - lane) / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
 }
 
 // ---- the pose update of the rows with the next pass's bounds and group lists -------------------------------------------
@@ -242,7 +267,7 @@ __global__ __launch_bounds__(256) void k_transform_cull(const double *in, const 
     if (!rb.ub) return;
     double lo[3], hi[3], ubg;
     row_bound_store(rb, i, valid, p[0], p[1], p[2], have, t[0], t[1], t[2], lo, hi, ubg);
-    if (gl.cnt) block_cull(cl, i / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
+    if (gl.cnt) block_cull(cl, (i - lane) / kGroupRows, lo, hi, ubg, frames, nsplits, gl, lane);
 }
 
 // Single GPU: final sum + step + pose update of the rows (k_finish_step_transform, kernels.h) + the rows' bounds and the
@@ -366,17 +391,17 @@ __global__ __launch_bounds__(256) void k_step_transform_cull(const double *in, d
     }
 }
 
-// ---- normal estimation: the groups are runs of 64 sorted target rows, their bound the largest of the rows' own ----------
-// (k_knn_prebound's T: the k-th neighbour of every row lies within it).  One wave per group; rows = sorted positions
-// row0 .. row0 + nrows, groups and bounds numbered from the launch's first row (row0 a multiple of 64).
+// ---- normal estimation: the groups are runs of 32 sorted target rows, their bound the largest of the rows' own ----------
+// (k_knn_prebound's T: the k-th neighbour of every row lies within it).  One wave per pair of groups; rows = sorted
+// positions row0 .. row0 + nrows, groups and bounds numbered from the launch's first row (row0 a multiple of 64).
 __global__ __launch_bounds__(1024) void k_knn_group_cull(const double *__restrict__ sorted, int m, int ms, int row0, int nrows,
                                                         const double *__restrict__ t_row, const SplitFrame *__restrict__ frames,
                                                         int nsplits, const GroupLists gl)
 {
     __shared__ CullLds cl;
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 16 + (threadIdx.x >> 6);
-    const int local = g * kGroupRows + lane;
+    const int w = blockIdx.x * 16 + (threadIdx.x >> 6); // the wave's 64 rows: groups 2 w and 2 w + 1
+    const int local = w * 64 + lane;
     const int j = row0 + local;
     const bool valid = local < nrows && j < m;
     double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308}, ub = 0.0;
@@ -388,11 +413,11 @@ __global__ __launch_bounds__(1024) void k_knn_group_cull(const double *__restric
             ub = t == t ? t : __builtin_inf();
         }
     }
-    block_cull(cl, g, lo, hi, ub, frames, nsplits, gl, lane); // (a wave past the last group brings an empty box)
+    block_cull(cl, 2 * w, lo, hi, ub, frames, nsplits, gl, lane); // (a wave past the last group brings empty boxes)
 }
 
 // ---- the coarse pass over the group lists ------------------------------------------------------------------------------
-// One (row group, split) pair per wave, WAVES pairs of the SAME split per workgroup: the unit of nn_mfma.h (operands of the
+// Two (row group, split) pairs per wave -- its two 32-row tiles, any two of the list -- 2 WAVES pairs of the SAME split per workgroup: the unit of nn_mfma.h (operands of the
 // split staged through LDS in two chunks, 128 MFMAs per wave, MODE 2 epilogue) with each wave's rows taken from the
 // split's list.  A fixed grid strides over the chunks of all lists: chunk c belongs to the split s with
 // pre[s] <= c < pre[s + 1], pre = the running sum of ceil(cnt[s] / WAVES) -- formed by every workgroup for itself (a few
@@ -429,7 +454,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
         for (int s0 = 0; s0 < nsplits; s0 += 64) {
             const int s = s0 + lane;
             const unsigned c = s < nsplits ? cnt[s] : 0u;
-            const unsigned ch = (c + WAVES - 1) / WAVES;
+            const unsigned ch = (c + 2 * WAVES - 1) / (2 * WAVES);
             unsigned inc = ch, tot = c;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -462,8 +487,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
     stamp[1] = __builtin_amdgcn_s_memrealtime();
 #endif
     const unsigned total = pre[nsplits];
-    // chunk c -> its split, and this wave's list entry (requested, not waited for)
-    auto lookup = [&](const unsigned c, int &s, bool &active, unsigned &gv) {
+    // chunk c -> its split, and this wave's two list entries (requested, not waited for)
+    auto lookup = [&](const unsigned c, int &s, bool &active, bool &active_b, uint2 &gv) {
         int slo = 0, shi = nsplits; // pre[slo] <= c < pre[shi]
         while (shi - slo > 1) {
             const int mid = (slo + shi) >> 1;
@@ -471,24 +496,27 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
             else shi = mid;
         }
         s = __builtin_amdgcn_readfirstlane(slo);
-        const unsigned item = (c - pre[s]) * WAVES + (unsigned)wave;
+        const unsigned item = (c - pre[s]) * (2 * WAVES) + 2u * (unsigned)wave; // (even: cap is even, the pair is 8-byte aligned)
         active = item < lcnt[s];
-        gv = active ? items[(size_t)s * cap + item] : 0u;
+        active_b = item + 1u < lcnt[s];
+        gv = active ? *reinterpret_cast<const uint2 *>(items + (size_t)s * cap + item) : make_uint2(0u, 0u);
     };
     unsigned c = blockIdx.x;
 #pragma unroll 1
     while (c < total) {
-        unsigned gv = 0u;
+        uint2 gv = make_uint2(0u, 0u);
         int s = 0;
-        bool active = false;
-        lookup(c, s, active, gv);
-        const int g = __builtin_amdgcn_readfirstlane((int)gv);
+        bool active = false, active_b = false;
+        lookup(c, s, active, active_b, gv);
+        const int g = __builtin_amdgcn_readfirstlane((int)gv.x);
+        // (a wave with one tile only -- the odd last entry of a list: the second tile's rows lie past the end, nothing of it is listed)
+        const int gb = active_b ? __builtin_amdgcn_readfirstlane((int)gv.y) * kGroupRows : n;
 #ifdef ICPMI_GROUPS_CLOCKS
         if (nchunk < 3) stamp[2 + 2 * nchunk] = __builtin_amdgcn_s_memrealtime();
         if (nchunk == 0) stamp[8] = (unsigned long long)s | ((unsigned long long)__popcll(__ballot(active)) << 32);
 #endif
         coarse_unit_rows<2, kCoarseQT, WAVES, QSOA>(lds, g * kGroupRows, active, s, nsplits, qry, n, qstride, Bpack, frames, nullptr, nullptr,
-                                                    kl);
+                                                    kl, 0, gb);
         __syncthreads(); // the epilogue's LDS is the next chunk's operand buffer; everybody has read next_chunk
 #ifdef ICPMI_GROUPS_CLOCKS
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -455,17 +455,21 @@ constexpr int kNnEntCap = 8;
 // wave), and every lane picks up its fragment: row l&31 of the tile, slots 8*(l>>5) .. +7.
 // QSOA: the queries are an SoA array (x[0..n) | y | z with component stride `qstride`, the layout of
 // the sorted target) instead of the rows of an N x 3 array.
+// `q0b` >= 0 (QT == 2): the wave's second 32-row tile starts at row q0b instead of q0 + 32 (the culled engine hands a
+// wave any two tiles of a split's list, nn_culled.h).
 template <int QT, bool QSOA>
 __device__ __forceinline__ void coarse_build_a(uint4 *rows, const int lane, const int q0,
                                                const double *__restrict__ qry, const int n, const size_t qstride,
                                                const double c0, const double c1, const double c2,
-                                               bf16x8 (&afrag)[QT], float (&pn)[(QT + 1) / 2], float (&p2)[(QT + 1) / 2])
+                                               bf16x8 (&afrag)[QT], float (&pn)[(QT + 1) / 2], float (&p2)[(QT + 1) / 2],
+                                               const int q0b = -1)
 {
     static_assert(QT == 1 || QT % 2 == 0, "operands are staged 64 queries at a time (QT = 1: 32, by both half-waves)");
 #pragma unroll
     for (int gq = 0; gq < (QT + 1) / 2; ++gq) {
         const int ql = QT == 1 ? (lane & 31) : lane; // QT = 1: lanes 32.. repeat the rows of lanes 0..31
-        const int iq = q0 + gq * 64 + ql < n ? q0 + gq * 64 + ql : n - 1;
+        const int ir = (QT == 2 && q0b >= 0 && lane >= 32) ? q0b + (lane - 32) : q0 + gq * 64 + ql;
+        const int iq = ir < n ? ir : n - 1;
         const float px = (float)((QSOA ? qry[iq] : qry[3 * iq]) - c0),
                     py = (float)((QSOA ? qry[qstride + iq] : qry[3 * iq + 1]) - c1),
                     pz = (float)((QSOA ? qry[2 * qstride + iq] : qry[3 * iq + 2]) - c2);
@@ -526,7 +530,7 @@ template <int MODE, int QT>
 __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const int q0, const int s, const int nsplits,
                                                 const int n, const f32x16 (&m)[QT], const float (&pn)[(QT + 1) / 2],
                                                 float2 *__restrict__ coarse, float *__restrict__ slotmin,
-                                                const KnnLists &kl, const float (&thr)[(QT + 1) / 2])
+                                                const KnnLists &kl, const float (&thr)[(QT + 1) / 2], const int q0b = -1)
 {
     const int ql = lane & 31, half = lane >> 5;
 #pragma unroll
@@ -550,7 +554,7 @@ __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const int iq = q0 + t * 32 + ql;
+        const int iq = (QT == 2 && q0b >= 0 && t == 1) ? q0b + ql : q0 + t * 32 + ql;
         if (MODE == 2) {
             // Nearly every (row, split) pair has nothing under the row's bound: one minimum over the lane's 16
             // columns, one compare, one ballot.  (+Inf / NaN of a far-away or NaN row become kBig like in MODE 1;
@@ -632,7 +636,8 @@ __device__ __forceinline__ void coarse_unit_rows(uint4 *lds, const int q0, const
                                                  const uint4 *__restrict__ Bpack,
                                                  const SplitFrame *__restrict__ frames,
                                                  float2 *__restrict__ coarse, float *__restrict__ slotmin,
-                                                 const KnnLists kl = KnnLists{nullptr, nullptr, nullptr, nullptr, 0}, const int bx = 0)
+                                                 const KnnLists kl = KnnLists{nullptr, nullptr, nullptr, nullptr, 0}, const int bx = 0,
+                                                 const int q0b = -1 /* >= 0: the wave's second tile starts there (coarse_build_a) */)
 {
     constexpr int THREADS = 64 * WAVES;
     constexpr int CHUNK16 = kChunkTiles * 64;  // uint4 per staged chunk (32 KiB)
@@ -650,7 +655,7 @@ __device__ __forceinline__ void coarse_unit_rows(uint4 *lds, const int q0, const
 
     bf16x8 afrag[QT];
     float pn[(QT + 1) / 2] = {}, p2[(QT + 1) / 2] = {}, thr[(QT + 1) / 2];
-    if (active) coarse_build_a<QT, QSOA>(lds + wave * (64 * 2), lane, q0, qry, n, qstride, c0, c1, c2, afrag, pn, p2);
+    if (active) coarse_build_a<QT, QSOA>(lds + wave * (64 * 2), lane, q0, qry, n, qstride, c0, c1, c2, afrag, pn, p2, q0b);
 #pragma unroll
     for (int gq = 0; gq < (QT + 1) / 2; ++gq) {
         thr[gq] = 0.f;
@@ -660,7 +665,8 @@ __device__ __forceinline__ void coarse_unit_rows(uint4 *lds, const int q0, const
             // covers this evaluation's own roundings and tau_from_a's 5e-6.  A NaN bound (a row with a non-finite coordinate)
             // gives a NaN threshold, under which nothing is; an infinite one (no previous match) lists everything.
             const int ql = QT == 1 ? (lane & 31) : lane;
-            const int iq = q0 + gq * 64 + ql < n ? q0 + gq * 64 + ql : n - 1;
+            const int ir = (QT == 2 && q0b >= 0 && lane >= 32) ? q0b + (lane - 32) : q0 + gq * 64 + ql;
+            const int iq = ir < n ? ir : n - 1;
             const float ubf = kl.thr[iq], sqf = kl.sq[iq];
             const float a = (__builtin_amdgcn_sqrtf(p2[gq]) + (float)frames[s].rho) * 1.0001f;
             const float eps = 1.5260e-05f * a;
@@ -700,7 +706,7 @@ __device__ __forceinline__ void coarse_unit_rows(uint4 *lds, const int q0, const
     if (active)
 #endif
         coarse_epilogue<MODE, QT>(reinterpret_cast<float *>(lds) + wave * (32 * 36), lane, q0, s, nsplits, n, m, pn, coarse,
-                                  slotmin, kl, thr);
+                                  slotmin, kl, thr, q0b);
 #ifdef ICPMI_COARSE_CLOCKS
     if (MODE == 0 && slotmin && threadIdx.x == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(slotmin) + 4 * ((size_t)bx * nsplits + s);
@@ -1041,22 +1047,6 @@ __device__ __forceinline__ void resolve_certify(const float (&pv)[KEEP > 0 ? KEE
 #define ICPMI_RESOLVE_WW 4 /* waves per workgroup = Q * WW queries per partial row of normal-equation terms */
 #endif
 constexpr int kResolveWW = ICPMI_RESOLVE_WW;
-// A second level for the normal-equation sums of the large-cloud resolve kernels (round 4).  Every resolve workgroup
-// leaves one partial row (64 queries); at C3 the kernel that follows -- every one of its ~100 workgroups -- summed 1,563 of
-// them (400 KB through one CU, four rounds of loads: 6.7 of its 17 us), at 1M rows 15,625.  Now the workgroup that is
-// the LAST of its group of kSumGroup consecutive ones to finish adds the group's rows, in index order whoever arrives
-// last, into one row of `rows2`: the step kernels read ceil(nblocks / kSumGroup) rows.  The hand-off is the usual one:
-// every writer fences its row, one thread takes a ticket with an agent-scope atomic, the last arriver fences again and
-// reads the rows past its CU's L1 (agent-scope atomic loads), and puts the ticket back to zero for the next pass.
-// The order of the additions is fixed, so the sums stay run-to-run bit-stable; it is a different order from round 3's
-// (the history's last bits moved once, inside every tolerance of the tests).  rows2 == nullptr: one level, as before
-// (the quarter-wave kernels of the small-cloud regime, whose few hundred rows are one round of loads).
-constexpr int kSumGroup = 16;
-struct SumTree {
-    double *rows2;       // [ceil(nblocks / kSumGroup)][kSumsStride]
-    unsigned *tickets;   // [ceil(nblocks / kSumGroup)], zero between launches
-    int nblocks;         // workgroups (first-level rows) of the launch
-};
 // The end of the Q-queries-per-wave resolve kernels (k_nn_resolve, k_nn_resolve_bounded): results out, counters, and the
 // fused residual + normal-equation terms.  (jspec, q*, n*): the matched target and normal gathered ahead for target
 // `jspec` (< 0: nothing was gathered).
@@ -1068,8 +1058,7 @@ __device__ __forceinline__ void resolve_finish(const int lane, const int wave, c
                                                const unsigned extra_slots, const unsigned extra_splits,
                                                const double *__restrict__ tgt_orig, const double *__restrict__ nrm,
                                                double *__restrict__ partials, const int jspec, double q0, double q1,
-                                               double q2, double n0, double n1, double n2,
-                                               const SumTree tree = SumTree{nullptr, nullptr, 0})
+                                               double q2, double n0, double n1, double n2)
 {
     if (valid && sub == 0) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
@@ -1154,30 +1143,6 @@ __device__ __forceinline__ void resolve_finish(const int lane, const int wave, c
             for (int w = 4; w < kResolveWW; ++w) v += red[w][e];
             partials[(size_t)blockIdx.x * kSumsStride + e] = v;
         }
-        if (tree.rows2) { // (uniform over the launch)
-            __shared__ int last_of_group;
-            __threadfence(); // this thread's part of the row is visible to the whole device ...
-            __syncthreads(); // ... and so is everybody else's, before the ticket is taken
-            const int grp = blockIdx.x / kSumGroup;
-            const int members = tree.nblocks - grp * kSumGroup < kSumGroup ? tree.nblocks - grp * kSumGroup : kSumGroup;
-            if (threadIdx.x == 0) {
-                const unsigned t = __hip_atomic_fetch_add(tree.tickets + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last_of_group = t == (unsigned)(members - 1);
-                if (last_of_group) __hip_atomic_store(tree.tickets + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            if (last_of_group) {
-                __threadfence();
-                if (threadIdx.x < 28) {
-                    const int e = threadIdx.x;
-                    const double *rows = partials + (size_t)grp * kSumGroup * kSumsStride + e;
-                    double v = __hip_atomic_load(rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (int r = 1; r < members; ++r)
-                        v += __hip_atomic_load(rows + (size_t)r * kSumsStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    tree.rows2[(size_t)grp * kSumsStride + e] = v;
-                }
-            }
-        }
     }
 }
 
@@ -1230,8 +1195,7 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
                                                     double *__restrict__ partials,
                                                     const int *__restrict__ blk_cnt,
                                                     const int *__restrict__ blk_list,
-                                                    const IcpState *__restrict__ st,
-                                                    const SumTree tree = SumTree{nullptr, nullptr, 0})
+                                                    const IcpState *__restrict__ st)
 {
     static_assert(Q == 16 || Q == 32, "queries per wave");
     constexpr int SUBS = 64 / Q;   // lanes per query
@@ -1346,7 +1310,7 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     resolve_certify<SUBS, Q, KEEP, ICPMI_RESOLVE_SCANBATCH>(pv, lane, sub, valid, ic, n, px, py, pz, coarse, splits, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                              bd, bj, extra_slots, extra_splits);
     resolve_finish<Q>(lane, wave, ql, sub, i, valid, bd, bj, px, py, pz, m, idx, d2out, counters, extra_slots, extra_splits,
-                      tgt_orig, nrm, partials, jspec, q0, q1, q2, n0, n1, n2, tree);
+                      tgt_orig, nrm, partials, jspec, q0, q1, q2, n0, n1, n2);
 }
 
 // The end of the quarter-wave resolve kernels (k_nn_resolve4, k_nn_resolve4_bounded): results out, counters, and the fused

@@ -1,5 +1,6 @@
-"""A few icpmi_align calls on the C2 stand-in (LiDAR-like pair, ~9k x 11k points), for rocprofv3.
-Usage: python scripts/run_c2_once.py [engine] [calls]"""
+"""A few icpmi_align calls on the C2 stand-in (LiDAR-like pair, ~9k x 11k points at the 0.5 m voxel; ~18k x 20k at 0.3 m,
+the size BASELINE.json configs[1] names), for rocprofv3.
+Usage: python scripts/run_c2_once.py [engine] [calls] [voxel]"""
 import os, sys
 import numpy as np
 import torch
@@ -8,7 +9,8 @@ from lidar_slam_from_scratch_amd import capi, synth
 
 eng = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-src, tgt, _ = synth.c2_lidar_pair()
+voxel = float(sys.argv[3]) if len(sys.argv) > 3 else 0.5
+src, tgt, _ = synth.c2_lidar_pair(voxel=voxel)
 dsrc = torch.from_numpy(src).cuda()
 dtgt = torch.from_numpy(tgt).cuda()
 cfg = capi.Context.make_config()
