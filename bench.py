@@ -109,8 +109,8 @@ def cpu_baseline(src, tgt, steps):
 
 
 def measure_traffic(points, search, timeout_s=75):
-    """HBM bytes per launch of the dominant kernel (k_nn_coarse_bounded: the all-pairs pass of every ICP iteration but
-    a call's first, which is k_nn_coarse<0>), measured in this run: two
+    """HBM bytes per launch of the dominant kernel (k_nn_coarse_bounded: the all-pairs pass of every ICP iteration),
+    measured in this run: two
     `rocprofv3 --kernel-trace --pmc <counter>` passes in child processes -- FETCH_SIZE and WRITE_SIZE
     do not fit one pass (MI355X_MICROARCH.md, rocprofv3 PMC slots) -- over scripts/run_align_once.py
     on the same workload.  Both counters come in KiB.  gfx950 correction from the same guide:
@@ -131,14 +131,28 @@ def measure_traffic(points, search, timeout_s=75):
         out_dir = tempfile.mkdtemp(prefix="icpmi_pmc_", dir="/tmp")
         cmd = [rocprof, "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", out_dir, "--",
                sys.executable, os.path.join(ROOT, "scripts", "run_align_once.py"), str(search), str(points), "6", "2"]
+        # bounded: the headline must not wait long for the profiler (a pass takes ~15 s, most of it the child's
+        # `import torch`); a pass that does not finish leaves traffic = null.  The pass runs in a session of its own
+        # and a timeout ends the whole process GROUP: killing the rocprofv3 wrapper alone would leave the profiled
+        # child on the GPU behind the headline
+        import signal
         try:
-            # bounded: the headline must not wait long for the profiler (a pass takes ~15 s, most of it
-            # the child's `import torch`); a pass that does not finish leaves traffic = null
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
-                               stderr=subprocess.STDOUT, timeout=timeout_s)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                                    stderr=subprocess.STDOUT, start_new_session=True)
         except Exception:  # noqa: BLE001
             shutil.rmtree(out_dir, ignore_errors=True)
             return None
+        try:
+            proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            proc.wait()
+            shutil.rmtree(out_dir, ignore_errors=True)
+            return None
+        r = proc
         vals, first = [], []
         for f in glob.glob(out_dir + "/**/*counter_collection.csv", recursive=True):
             for row in csv.DictReader(open(f)):
@@ -156,7 +170,7 @@ def measure_traffic(points, search, timeout_s=75):
     return {"hbm_bytes_per_launch": int((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0),
             "FETCH_SIZE_KiB": kib["FETCH_SIZE"], "WRITE_SIZE_KiB": kib["WRITE_SIZE"],
             "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one pass each) over scripts/run_align_once.py, "
-                   "mean over the k_nn_coarse_bounded launches (every pass of a call but its first); fetch doubled (gfx950 "
+                   "mean over the k_nn_coarse_bounded launches (every pass of a call); fetch doubled (gfx950 "
                    "wide-read correction)"}
 
 

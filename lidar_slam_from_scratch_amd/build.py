@@ -11,6 +11,10 @@ _SOURCES = ["capi.hip", "sort.hip", "kernels.h", "device_math.h", "nn_mfma.h", "
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True
+    # a -D variant left in place by a sweep script that did not get to restore the product build
+    stamp = os.path.join(CSRC, ".build_flags")
+    if os.path.exists(stamp) and open(stamp).read().strip():
+        return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in _SOURCES]
     deps.append(os.path.join(_HERE, "..", "include", "icp_mi355x.h"))
@@ -20,8 +24,9 @@ def _stale():
 def build_library(force=False, verbose=False):
     """Compile with hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
     if force or _stale():
-        cmd = ["make", "-C", CSRC, "OUT=" + LIB_PATH]
-        if force:
+        cmd = ["make", "-C", CSRC, "OUT=" + LIB_PATH, "EXTRA="]
+        stamp = os.path.join(CSRC, ".build_flags")
+        if force or (os.path.exists(stamp) and open(stamp).read().strip()):
             cmd.insert(1, "-B")
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if verbose or out.returncode != 0:

@@ -451,18 +451,35 @@ int small_max_queries()
     }();
     return v;
 }
+// The small-cloud kernel's workgroup takes 32 rows through ALL splits, so its time grows with rows x splits where the
+// general path's grows with the units on the chip: measured (scripts/engine_threshold.py, profiles/r4_final/
+// engine_threshold.json: registrations of n -> n points by the three paths) it wins or ties up to 7 splits (14k points:
+// 0.385 against 0.416 ms on a LiDAR-like pair), ties at 10 and loses from 14 (uniform 28k: 1.03 against 0.93 ms).
+// ICPMI_SMALL_MAX_SPLITS moves the limit (at most kSmallMaxSplits, what the kernel's LDS records hold).
+constexpr int kSmallSplitsDefault = 8;
+int small_max_splits()
+{
+    static const int v = [] {
+        if (const char *e = getenv("ICPMI_SMALL_MAX_SPLITS")) {
+            const long x = strtol(e, nullptr, 10);
+            if (x >= 0 && x <= kSmallMaxSplits) return (int)x;
+        }
+        return kSmallSplitsDefault;
+    }();
+    return v;
+}
 // (by the target alone: whether its Morton-ordered normals are worth keeping)
 bool small_target(const icpmi_ctx *ctx)
 {
-    return small_enabled() && ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && !ctx->nn_pruned && ctx->nn_splits <= kSmallMaxSplits;
+    return small_enabled() && ctx->nn_engine == ICPMI_SEARCH_MFMA_BF16 && !ctx->nn_pruned && ctx->nn_splits <= small_max_splits();
 }
 
 // Choose and prepare the search engine for a target cloud (once per call: the target does
 // not move).  Both engines return the same indices; AUTO takes the MFMA engine once the
 // pair count makes its fixed costs (Morton sort, operand packing, resolve) worthwhile.
 // AUTO: the exact fp64 kernels for tiny clouds; the MFMA engine from 256 targets -- over all pairs while the target is
-// the handful of splits the small-cloud kernel takes (icp_small.h), culled (nn_culled.h) beyond: the same correspondences
-// bit for bit, 84-95 % of the (row group, split) pairs never evaluated (round 4; ICPMI_AUTO_CULLED=0 keeps AUTO on the
+// a dozen splits or fewer (the small-cloud kernel of icp_small.h up to 8, the general kernels to 12), culled
+// (nn_culled.h) beyond: the same correspondences bit for bit, 90-98 % of the (row tile, split) pairs never evaluated (round 4; ICPMI_AUTO_CULLED=0 keeps AUTO on the
 // all-pairs engine everywhere, the A/B knob).
 bool auto_culled_enabled()
 {
@@ -472,13 +489,27 @@ bool auto_culled_enabled()
     }();
     return v;
 }
+// (targets of more than this many splits; ICPMI_AUTO_CULLED_FROM moves it.  scripts/engine_threshold.py: at 10 splits the
+// culled engine's own fixed costs -- the rows' Morton sort, the lists -- still lose to the all-pairs kernels by 5-7 %, at 14
+// it wins by 7-13 %, at 49 by 2.3-3.1x)
+int auto_culled_from_splits()
+{
+    static const int v = [] {
+        if (const char *e = getenv("ICPMI_AUTO_CULLED_FROM")) {
+            const long x = strtol(e, nullptr, 10);
+            if (x >= 0 && x <= 1000000) return (int)x;
+        }
+        return 12;
+    }();
+    return v;
+}
 int engine_for(const icpmi_ctx *ctx, int m, int n_hint)
 {
     int engine = ctx->opt.search;
     const int splits = (m + kSplitTargets - 1) / kSplitTargets;
     if (engine == ICPMI_SEARCH_AUTO) {
         engine = (m >= mfma_min_targets() && n_hint >= kMfmaMinQueries) ? ICPMI_SEARCH_MFMA_BF16 : ICPMI_SEARCH_EXACT_F64;
-        if (engine == ICPMI_SEARCH_MFMA_BF16 && splits > kSmallMaxSplits && auto_culled_enabled()) engine = ICPMI_SEARCH_MFMA_PRUNED;
+        if (engine == ICPMI_SEARCH_MFMA_BF16 && splits > auto_culled_from_splits() && auto_culled_enabled()) engine = ICPMI_SEARCH_MFMA_PRUNED;
     }
     // (the culled coarse kernel keeps a running sum over the splits in LDS: beyond kCullMaxSplits -- 8.4M targets -- all pairs)
     if (engine == ICPMI_SEARCH_MFMA_PRUNED && splits > kCullMaxSplits) engine = ICPMI_SEARCH_MFMA_BF16;
@@ -516,8 +547,14 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     hipStream_t s = ctx->stream;
     Range range("icpmi:target_prepass");
     StageTimer t(ctx, ST_SETUP);
-    hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_tgt, m, (double *)ctx->bbox_part.p, 1);
-    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, frame);
+    unsigned long long *stat3 = (unsigned long long *)((char *)ctx->nn_misc.p + 128); // the resolve's statistics words of the coming call
+    if (m <= kBboxSingleMax)
+        hipLaunchKernelGGL(k_bbox_single, dim3(1), dim3(1024), 0, s, d_tgt, m, frame, 1, stat3);
+    else {
+        hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_tgt, m, (double *)ctx->bbox_part.p, 1);
+        hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, frame);
+        HIP_TRY(ctx, hipMemsetAsync(stat3, 0, 24, s));
+    }
     hipLaunchKernelGGL(k_morton_keys, dim3((m + 255) / 256), dim3(256), 0, s, d_tgt, m, (const NnFrame *)frame,
                        keys_in, vals_in);
     HIP_TRY(ctx, sort_pairs_u32(ctx->sort_tmp.p, &sort_bytes, keys_in, keys_out, vals_in, perm, (unsigned)m, s));
@@ -528,7 +565,6 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     hipLaunchKernelGGL(k_pack_targets, dim3((splits * kSplitTiles * 64 + 255) / 256), dim3(256), 0, s,
                        (const double *)ctx->tgt_sorted.p, m, ms, (const SplitFrame *)ctx->frames.p,
                        (uint4 *)ctx->bpack.p, splits);
-    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->nn_misc.p + 128, 0, 24, s));
     HIP_TRY(ctx, hipGetLastError());
     return ICPMI_OK;
 }
@@ -1257,7 +1293,7 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // (from 4,096 rows: below, the Morton sort of the rows costs a call more than its passes gain)
     // (not where ICPMI_SMALL=0 puts the general kernels in the small-cloud kernel's place: there they keep its order of rows,
     // hence its bits)
-    const bool small_regime = !sharded_run && n <= small_max_queries() && ctx->nn_splits <= kSmallMaxSplits;
+    const bool small_regime = !sharded_run && n <= small_max_queries() && ctx->nn_splits <= small_max_splits();
     const bool sorted_rows_loop = fused && !pruned && !small && !small_regime && n >= 4096 && resolve_waves(n) != -32;
     size_t sort_bytes = 0;
     if (pruned || sorted_rows_loop) {
@@ -1277,8 +1313,12 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         unsigned *keys_in = (unsigned *)ctx->src_sort.p, *keys_out = keys_in + n, *vals_in = keys_in + 2 * (size_t)n,
                  *perm = keys_in + 3 * (size_t)n;
         StageTimer t(ctx, ST_SETUP);
-        hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_src, n, (double *)ctx->bbox_part.p, 1);
-        hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, sframe);
+        if (n <= kBboxSingleMax)
+            hipLaunchKernelGGL(k_bbox_single, dim3(1), dim3(1024), 0, s, d_src, n, sframe, 1, (unsigned long long *)nullptr);
+        else {
+            hipLaunchKernelGGL(k_bbox_partial, dim3(bblocks), dim3(256), 0, s, d_src, n, (double *)ctx->bbox_part.p, 1);
+            hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, s, (const double *)ctx->bbox_part.p, bblocks, sframe);
+        }
         hipLaunchKernelGGL(k_morton_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_src, n, (const NnFrame *)sframe,
                            keys_in, vals_in);
         HIP_TRY(ctx, sort_pairs_u32(ctx->sort_tmp.p, &sort_bytes, keys_in, keys_out, vals_in, perm, (unsigned)n, s));

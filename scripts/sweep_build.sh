@@ -3,6 +3,9 @@
 # flag set on the GPU box and prints the per-kernel averages of one C3 run (engine $ENGINE, default 0).
 set -e
 cd "$GRAFT_REPO_ROOT"
+# (the product build comes back whatever ends this script; the Makefile's .build_flags stamp covers a SIGKILL: build.py rebuilds)
+trap 'rm -f lidar_slam_from_scratch_amd/csrc/capi.o; make -s -C lidar_slam_from_scratch_amd/csrc EXTRA= > /dev/null 2>&1' EXIT
+trap 'exit 143' TERM INT HUP
 for flags in "$@"; do
     rm -f lidar_slam_from_scratch_amd/csrc/capi.o
     make -s -C lidar_slam_from_scratch_amd/csrc EXTRA="$flags" > /dev/null 2>&1

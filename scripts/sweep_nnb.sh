@@ -2,6 +2,9 @@
 # where k_nn_resolve_bounded's time goes: rebuild with -DICPMI_NNB_STOP=<phase> (results are WRONG in those builds:
 # timing only; only the FIRST bounded pass sees sane inputs, so 2 iterations) and time the kernel on C3.
 cd "$GRAFT_REPO_ROOT"
+# (the product build comes back whatever ends this script; the Makefile's .build_flags stamp covers a SIGKILL: build.py rebuilds)
+trap 'rm -f lidar_slam_from_scratch_amd/csrc/capi.o; make -s -C lidar_slam_from_scratch_amd/csrc EXTRA= > /dev/null 2>&1' EXIT
+trap 'exit 143' TERM INT HUP
 for flags in "$@"; do
     rm -f lidar_slam_from_scratch_amd/csrc/capi.o
     make -s -C lidar_slam_from_scratch_amd/csrc EXTRA="$flags" > /dev/null 2>&1

@@ -2,6 +2,9 @@
 # A/B of the resolve kernels: rebuild with -DICPMI_RESOLVE_WAVES=<w> and time k_nn_resolve* on
 # C3 (all-pairs, pruned), one 12.5k-row shard of it, and the C2 pair.
 cd "$GRAFT_REPO_ROOT"
+# (the product build comes back whatever ends this script; the Makefile's .build_flags stamp covers a SIGKILL: build.py rebuilds)
+trap 'rm -f lidar_slam_from_scratch_amd/csrc/capi.o; make -s -C lidar_slam_from_scratch_amd/csrc EXTRA= > /dev/null 2>&1' EXIT
+trap 'exit 143' TERM INT HUP
 for w in "$@"; do
     rm -f lidar_slam_from_scratch_amd/csrc/capi.o
     make -s -C lidar_slam_from_scratch_amd/csrc EXTRA="-DICPMI_RESOLVE_WAVES=$w" > /dev/null 2>&1

@@ -3,6 +3,9 @@
 # -DICPMI_RESOLVE_SCANBATCH).  Per build: k_nn_resolve4<8> on 40 LiDAR-like frames, k_nn_resolve<16> on C3.
 # usage (GPU box): bash scripts/sweep_scan.sh "<flags A>" "<flags B>" ...
 cd "$GRAFT_REPO_ROOT"
+# (the product build comes back whatever ends this script; the Makefile's .build_flags stamp covers a SIGKILL: build.py rebuilds)
+trap 'rm -f lidar_slam_from_scratch_amd/csrc/capi.o; make -s -C lidar_slam_from_scratch_amd/csrc EXTRA= > /dev/null 2>&1' EXIT
+trap 'exit 143' TERM INT HUP
 python - <<PY
 import sys; sys.path.insert(0, "scripts"); sys.path.insert(0, ".")
 import run_sequence

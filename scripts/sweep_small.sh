@@ -2,6 +2,9 @@
 # A/B builds on the two regimes at once: C3 (100k x 100k, k_nn_resolve) and a 12.5k-row shard of it
 # (k_nn_resolve4).  usage: scripts/sweep_small.sh "<EXTRA flags>" ...
 cd "$GRAFT_REPO_ROOT"
+# (the product build comes back whatever ends this script; the Makefile's .build_flags stamp covers a SIGKILL: build.py rebuilds)
+trap 'rm -f lidar_slam_from_scratch_amd/csrc/capi.o; make -s -C lidar_slam_from_scratch_amd/csrc EXTRA= > /dev/null 2>&1' EXIT
+trap 'exit 143' TERM INT HUP
 for flags in "$@"; do
     rm -f lidar_slam_from_scratch_amd/csrc/capi.o
     make -s -C lidar_slam_from_scratch_amd/csrc EXTRA="$flags" > /dev/null 2>&1

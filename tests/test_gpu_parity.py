@@ -933,7 +933,7 @@ print(json.dumps(out))
 
 
 def test_small_cloud_kernel_gives_the_general_path_bits():
-    """icp_small.h: for targets of at most 16 splits the rows' work of an iteration (pose update, coarse
+    """icp_small.h: for targets of at most 16 splits (AUTO uses it up to 8; ICPMI_SMALL_MAX_SPLITS=16 here) the rows' work of an iteration (pose update, coarse
     pass, resolve, normal-equation terms) is ONE kernel whose intermediate never leaves LDS.  Against the
     general path (ICPMI_SMALL=0: k_nn_coarse + k_nn_resolve4 + k_finish_step_transform) the partial rows
     are formed from the same correspondences in the same order, so pose, history and counts must agree
@@ -949,7 +949,7 @@ import sys, json
 sys.path.insert(0, %r)
 import numpy as np
 from lidar_slam_from_scratch_amd import capi, synth
-ctx = capi.Context(device=0, profile=1)
+ctx = capi.Context(device=0, profile=1, search=capi.SEARCH_MFMA_BF16)   # (AUTO would take the culled engine on the 15-split target)
 cases = {}
 for n in (300, 5000):
     cases["corner%%d" %% n] = synth.c1_room_corner(n)[:2] + (None,)
@@ -976,7 +976,7 @@ print(json.dumps(out))
 ''' % root
     legs = {}
     for knob in ("0", "1"):
-        env = dict(os.environ, ICPMI_SMALL=knob)
+        env = dict(os.environ, ICPMI_SMALL=knob, ICPMI_SMALL_MAX_SPLITS="16")
         r = subprocess.run([sys.executable, "-c", child], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
