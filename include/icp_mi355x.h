@@ -110,6 +110,9 @@ typedef struct {
     int64_t nn_group_pairs;                          /* culled engine: (32-row tile, 2048-target split) pairs of its passes ... */
     int64_t nn_group_pairs_run;                      /* ... and those within reach, the ones the coarse pass evaluated */
     double exchange_ms;  int64_t exchange_launches;  /* sharded runs: the per-pass all-reduce of 30 doubles alone (the launches bracketed) */
+    int64_t coarse_minima_bytes;                     /* bytes this context holds for (row, split) coarse minima (6 B each): only the
+                                                        stand-alone nearest-neighbour search and ICPMI_NN_BOUNDED=0 reserve any -- no
+                                                        registration does (a state, not a counter: icpmi_reset_profile leaves it) */
 } icpmi_profile;
 
 void icpmi_options_default(icpmi_options *opt);     /* device 0, normal_k 20 (icp.hpp:170), search AUTO or the

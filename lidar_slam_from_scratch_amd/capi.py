@@ -62,7 +62,7 @@ class Profile(C.Structure):
                 ("bounded_launches", C.c_int64),
                 ("nn_group_pairs", C.c_int64),
                 ("nn_group_pairs_run", C.c_int64),
-                ("exchange_ms", C.c_double), ("exchange_launches", C.c_int64)]
+                ("exchange_ms", C.c_double), ("exchange_launches", C.c_int64), ("coarse_minima_bytes", C.c_int64)]
 
 
 MAX_RANKS_INFO = 64

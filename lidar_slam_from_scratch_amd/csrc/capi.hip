@@ -221,6 +221,7 @@ struct icpmi_ctx {
     DevBuf sort_keys, sort_tmp, tgt_sorted, frames; // Morton pre-pass: keys/values, sorted copy, split frames
     DevBuf bpack, coarse, bbox_part, nn_misc; // MFMA engine: operands, coarse minima, frame + counters
     DevBuf src_sort;                          // Morton order of the source rows (the loop's internal order)
+
     DevBuf grp_cnt, grp_items;                // culled engine: per target split the list of 64-row groups within reach (nn_culled.h)
     bool nn_pruned = false;                   // the culled engine (ICPMI_SEARCH_MFMA_PRUNED; AUTO on large targets)
     int nn_engine = ICPMI_SEARCH_EXACT_F64;   // engine prepared for the current target
@@ -1308,6 +1309,9 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
         HIP_TRY(ctx, hipMemsetAsync(ctx->grp_cnt.p, 0, group_cnt_bytes(ctx), s));
     }
     if (pruned || sorted_rows_loop) {
+        // (Measured and not kept: this dozen of small launches on a stream of its own beside the target's pre-pass and normals
+        // -- 180 us off the call under rocprofv3, whose launch overhead starves the device at the head of a call, and nothing
+        // without it: 8,567 against 8,595 iterations/s at C3.)
         const int bblocks = std::max(1, std::min(256, (n + 255) / 256));
         NnFrame *sframe = (NnFrame *)((char *)ctx->nn_misc.p + 64);
         unsigned *keys_in = (unsigned *)ctx->src_sort.p, *keys_out = keys_in + n, *vals_in = keys_in + 2 * (size_t)n,
@@ -3126,6 +3130,7 @@ int icpmi_get_profile(icpmi_ctx *ctx, icpmi_profile *out)
         harvest_profile(ctx);
     }
     *out = ctx->prof;
+    out->coarse_minima_bytes = (int64_t)ctx->coarse.cap;
     return ICPMI_OK;
 }
 

@@ -237,11 +237,20 @@ def test_c4_eight_ranks_rehearsal(oracle):
     want_nrm = oracle.estimate_normals(tgt, None, 20, nthreads=nth)
     rows_of = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
     assert (rows_of(gathered) == rows_of(want_nrm)).all()
-    # the unsharded job on one context (2.9 GB of coarse minima), and the oracle loop
+    # the unsharded job on one context, and the oracle loop.  No pass of a registration keeps (row, split) coarse minima
+    # since round 4 (the first pass has a bound too): the buffer that was 2.9 GB here is not reserved at all, by either
+    # MFMA engine
     one = capi.Context(device=0)
     assert (one.estimate_normals(tgt, 20) == want_nrm).all()
     res1, hist1 = one.align(src, tgt, cfg)
+    assert one.get_profile()["coarse_minima_bytes"] == 0
     one.close()
+    allp = capi.Context(device=0, search=capi.SEARCH_MFMA_BF16)
+    res2, hist2 = allp.align(src, tgt, cfg)
+    assert allp.get_profile()["coarse_minima_bytes"] == 0
+    allp.close()
+    assert res2.num_iterations == n_it
+    np.testing.assert_allclose(hist2, hist1, rtol=0, atol=1e-12)
     assert res1.num_iterations == n_it
     np.testing.assert_allclose(hist, hist1, rtol=0, atol=1e-12)
     np.testing.assert_allclose(T, np.array(res1.transformation[:]).reshape(4, 4), rtol=0, atol=1e-12)
