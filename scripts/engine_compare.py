@@ -33,6 +33,8 @@ for name, eng in (("mfma_bf16", capi.SEARCH_MFMA_BF16), ("mfma_pruned", capi.SEA
     out[name] = {"ms_per_call": dt * 1e3, "it_per_s": res.loop_iterations / dt,
                  "loop_ms": p["loop_ms"] / reps, "coarse_ms_avg": p["coarse_ms"] / max(1, p["coarse_launches"]),
                  "pruned_frac": p["nn_pruned_blocks"] / max(1, p["nn_coarse_blocks"]),
+                 "pairs_culled_frac": (1.0 - p["nn_group_pairs_run"] / p["nn_group_pairs"]) if p["nn_group_pairs"] else 0.0,
+                 "coarse_minima_bytes": int(p["coarse_minima_bytes"]),
                  "pose_delta_vs_first": synth.pose_delta(T, ref[0]),
                  "hist_maxdiff": float(np.abs(hist - ref[1]).max())}
     ctx.close()

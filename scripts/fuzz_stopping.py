@@ -14,7 +14,12 @@ on every trial whose MARGIN exceeds 1e-12, where margin = the smallest distance 
 from flipping, min over the loop's iterations of | |prev - err| - tolerance | and | err - min_error |
 (scripts/iteration_sensitivity.py's measure, here taken from the oracle's own error history: the tests are functions of
 consecutive entries).  Trials under that margin are COUNTED and printed, not skipped silently: there an equal count is
-luck on both sides.  Pose and history are also held to the north_star's tolerances.
+luck on both sides.  Pose and history are also held to the north_star's tolerances (1e-4 m, 1e-4 rad; 1e-9 on the history)
+wherever the oracle's loop CONVERGED.  A loop that runs out of its 50 iterations without settling (frames three apart at 16
+beams: error 0.58 and oscillating, kappa 1e6) amplifies every rounding difference step by step: there the GPU is held to
+four times what the ORACLE ITSELF moves by when its sums are merely taken in reversed row order
+(scripts/iteration_sensitivity.py; seed 411087: the oracle moves 1.4e-4 m / 7.2e-5 rad / 1.4e-6 in the history, the GPU
+differs from it by 1.3e-4 / 6.7e-5 / 3.6e-7) -- counted and printed as "sensitive", counts and flags still equal.
 usage: python scripts/fuzz_stopping.py [trials] [first_seed]"""
 import os
 import sys
@@ -94,10 +99,36 @@ def check_case(seed, ctxs, cfg, stats):
                   % (seed, what, name, res.num_iterations, ref.num_iterations, bool(res.converged), ref.converged, len(hist),
                      len(ref.error_history), margin))
         elif same and (dt > 1e-4 or dr > 1e-4 or not np.allclose(hist, ref.error_history, rtol=0, atol=1e-9)):
-            bad += 1
-            print("MISMATCH stopping seed %d (%s) engine %s: pose %.3g m %.3g rad, history diff %.3g"
-                  % (seed, what, name, dt, dr, float(np.abs(np.asarray(hist) - np.asarray(ref.error_history)).max())))
+            hd = float(np.abs(np.asarray(hist) - np.asarray(ref.error_history)).max())
+            own = None if ref.converged else oracle_own_spread(src, tgt)
+            if own is not None and dt <= 4 * own[0] + 1e-12 and dr <= 4 * own[1] + 1e-12 and hd <= 4 * own[2] + 1e-12:
+                stats["sensitive"] = stats.get("sensitive", 0) + 1
+                print("SENSITIVE seed %d (%s) engine %s: an unsettled loop (50 iterations, not converged); pose %.3g m %.3g rad, history "
+                      "%.3g against the oracle, which itself moves by %.3g m %.3g rad %.3g under reversed summation"
+                      % (seed, what, name, dt, dr, hd, own[0], own[1], own[2]))
+            else:
+                bad += 1
+                print("MISMATCH stopping seed %d (%s) engine %s: pose %.3g m %.3g rad, history diff %.3g" % (seed, what, name, dt, dr, hd))
     return bad
+
+
+_own_cache = {}
+
+
+def oracle_own_spread(src, tgt):
+    """(pose m, pose rad, history) by which the oracle loop itself moves when every sum is taken in reversed row order."""
+    key = (src.shape[0], tgt.shape[0], float(src[0, 0]), float(tgt[0, 0]))
+    if key not in _own_cache:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import iteration_sensitivity as its
+        a = its.registration_margins(src, tgt, MAX_IT, TOL, MIN_ERR, order="index", nthreads=os.cpu_count() or 1)
+        b = its.registration_margins(src, tgt, MAX_IT, TOL, MIN_ERR, order="reversed", nthreads=os.cpu_count() or 1)
+        if a["num_iterations"] != b["num_iterations"]:
+            _own_cache[key] = (np.inf, np.inf, np.inf)   # the oracle's own count moves: nothing can be held
+        else:
+            dt, dr = synth.pose_delta(np.asarray(a["transformation"]), np.asarray(b["transformation"]))
+            _own_cache[key] = (dt, dr, float(np.abs(np.asarray(a["history"]) - np.asarray(b["history"])).max()))
+    return _own_cache[key]
 
 
 def new_stats():
@@ -122,8 +153,8 @@ def main(argv=None):
         if (t + 1) % 10 == 0:
             print("%d trials, %d mismatches, %d under the margin floor, %.0f s" % (t + 1, bad, stats["under"], time.time() - t0), flush=True)
     print("fuzz_stopping: %d trials x %d engines, %d mismatches; %d trials decided (smallest margin %.3g), %d under the 1e-12 floor, "
-          "%d ran out of iterations in the oracle" % (trials, len(ctxs), bad, stats["decided"], stats["min_margin"], stats["under"],
-                                                      stats["exhausted"]))
+          "%d ran out of iterations in the oracle, %d engine runs on unsettled loops held to the oracle's own spread"
+          % (trials, len(ctxs), bad, stats["decided"], stats["min_margin"], stats["under"], stats["exhausted"], stats.get("sensitive", 0)))
     for c in ctxs.values():
         c.close()
     return 1 if bad else 0
