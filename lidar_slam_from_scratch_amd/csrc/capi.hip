@@ -512,7 +512,7 @@ int engine_for(const icpmi_ctx *ctx, int m, int n_hint)
         engine = (m >= mfma_min_targets() && n_hint >= kMfmaMinQueries) ? ICPMI_SEARCH_MFMA_BF16 : ICPMI_SEARCH_EXACT_F64;
         if (engine == ICPMI_SEARCH_MFMA_BF16 && splits > auto_culled_from_splits() && auto_culled_enabled()) engine = ICPMI_SEARCH_MFMA_PRUNED;
     }
-    // (the culled coarse kernel keeps a running sum over the splits in LDS: beyond kCullMaxSplits -- 8.4M targets -- all pairs)
+    // (the culled coarse kernel keeps running sums over the splits in LDS: beyond kCullMaxSplits -- 6.3M targets -- all pairs)
     if (engine == ICPMI_SEARCH_MFMA_PRUNED && splits > kCullMaxSplits) engine = ICPMI_SEARCH_MFMA_BF16;
     return engine;
 }

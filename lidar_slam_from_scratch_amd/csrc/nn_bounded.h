@@ -102,10 +102,11 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
             const int jj = j0 + 16 * o, jc = jj < m ? jj : m - 1;
             const int oj = (int)perm[jc];
             const double dd = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), qx[r], qy[r], qz[r]);
-            if (act && jj < m && (dd < d[r] || (dd == d[r] && oj < jo[r]))) {
-                d[r] = dd;
-                jo[r] = oj;
-            }
+            // (selects, not branches: written with `if` and short-circuit operators every one of the sixteen updates of a
+            // lane became an exec-mask save, a branch and a restore -- 178 s_and_saveexec / 165 s_cbranch in the kernel)
+            const bool take = act & (jj < m) & ((dd < d[r]) | ((dd == d[r]) & (oj < jo[r])));
+            d[r] = take ? dd : d[r];
+            jo[r] = take ? oj : jo[r];
         }
     };
 #pragma unroll
@@ -146,10 +147,9 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
         for (int x = 1; x < 16; x <<= 1) {
             const double od = __shfl_xor(d[r], x, 64);
             const int oj = __shfl_xor(jo[r], x, 64);
-            if (od < d[r] || (od == d[r] && oj < jo[r])) {
-                d[r] = od;
-                jo[r] = oj;
-            }
+            const bool take = (od < d[r]) | ((od == d[r]) & (oj < jo[r]));
+            d[r] = take ? od : d[r];
+            jo[r] = take ? oj : jo[r];
         }
     }
 #pragma unroll
@@ -157,10 +157,9 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
         // query ql was scanned by quarter ql / ROUNDS in round ql % ROUNDS
         const double rd = __shfl(d[r], (ql / ROUNDS) * 16, 64);
         const int rj = __shfl(jo[r], (ql / ROUNDS) * 16, 64);
-        if ((ql % ROUNDS) == r && look && (rd < bd || (rd == bd && rj < bj))) {
-            bd = rd;
-            bj = rj;
-        }
+        const bool take = ((ql % ROUNDS) == r) & look & ((rd < bd) | ((rd == bd) & (rj < bj)));
+        bd = take ? rd : bd;
+        bj = take ? rj : bj;
     }
 
 #if defined(ICPMI_NNB_STOP) && ICPMI_NNB_STOP == 3
@@ -268,10 +267,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4_bounded(
             const int jj = j0 + 16 * o, jc = jj < m ? jj : m - 1; // (clamped: see k_nn_resolve_bounded)
             const int oj = (int)perm[jc];
             const double dd = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), px, py, pz);
-            if (act && jj < m && (dd < d || (dd == d && oj < jo))) {
-                d = dd;
-                jo = oj;
-            }
+            const bool take = act & (jj < m) & ((dd < d) | ((dd == d) & (oj < jo))); // (selects, not branches: k_nn_resolve_bounded)
+            d = take ? dd : d;
+            jo = take ? oj : jo;
         }
     };
     scan_slot(first_slot, ns > 0);
@@ -291,14 +289,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4_bounded(
     for (int x = 1; x < 16; x <<= 1) {
         const double od = __shfl_xor(d, x, 64);
         const int oj = __shfl_xor(jo, x, 64);
-        if (od < d || (od == d && oj < jo)) {
-            d = od;
-            jo = oj;
-        }
+        const bool take = (od < d) | ((od == d) & (oj < jo));
+        d = take ? od : d;
+        jo = take ? oj : jo;
     }
-    if (look && (d < bd || (d == bd && jo < bj))) {
-        bd = d;
-        bj = jo;
+    {
+        const bool take = look & ((d < bd) | ((d == bd) & (jo < bj)));
+        bd = take ? d : bd;
+        bj = take ? jo : bj;
     }
 
     // rows whose list did not fit: exhaustive search behind the split and slot boxes (see k_nn_resolve_bounded)

@@ -31,8 +31,10 @@ namespace icpmi {
 
 constexpr int kGroupRows = 32;          // rows per group: one 32-row MFMA tile (a wave of the coarse pass takes two, any two of a split's list)
 constexpr int kGroupStamps = 12;        // diagnostic build (-DICPMI_GROUPS_CLOCKS): words per workgroup of k_nn_coarse_groups
-constexpr int kCullMaxSplits = 4096;    // splits whose chunk prefix fits the coarse kernel's LDS (8.4M targets); beyond: all pairs
+constexpr int kCullMaxSplits = 3072;    // splits whose running sums fit the coarse kernel's LDS beside its 36 KiB of staging (2 x 3072 + 1 words of the 64 KiB a workgroup may have): 6.3M targets; beyond: all pairs
 static_assert(kGroupRows == kTile && kCoarseQT == 2, "a group is one tile; a wave of the coarse unit takes two");
+static_assert(sizeof(uint4) * CoarseLds<kCoarseWaves>::SCRATCH16 + sizeof(unsigned) * (2 * kCullMaxSplits + 1) + 64 <= 65536,
+              "k_nn_coarse_groups: staging + the running sums of kCullMaxSplits splits must fit a workgroup's 64 KiB of LDS");
 
 // One list of row groups per target split (the pairs that survived the box test), for the coming coarse pass.
 struct GroupLists {
