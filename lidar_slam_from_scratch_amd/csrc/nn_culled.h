@@ -53,9 +53,22 @@ struct GroupLists {
 // ~7,400 pairs of a C3 pass queued up on 49 addresses: 150 returning atomics per address, one after the other in the L2 --
 // the kernel took 29.6 us against the 16.9 of the form without lists.)  Must be called by every wave of the workgroup
 // (four barriers); a wave without rows passes lo = +big, hi = -big.
+constexpr int kCullLdsBoxes = 128; // targets of up to this many splits (262k points): the splits' boxes are staged in LDS
 struct CullLds {
     unsigned cnt[kCullMaxSplits];   // survivors of this workgroup per split, then the cursor inside its run
+    double box[kCullLdsBoxes][6];   // lo[3], hi[3] of every split (cull_stage_boxes), when they fit
 };
+// Requested early by the kernels that have a serial step in front of their box test (the boxes do not depend on the
+// pose): block_cull's first barrier publishes them.  As six strided 8-byte loads per (lane, split) -- twice, for the
+// count and for the placement -- the boxes were most of what the test added to its kernel.
+__device__ __forceinline__ void cull_stage_boxes(CullLds &lds, const SplitFrame *__restrict__ frames, const int nsplits)
+{
+    if (nsplits > kCullLdsBoxes) return;
+    for (int t = threadIdx.x; t < nsplits * 6; t += blockDim.x) {
+        const int s = t / 6, a = t - 6 * s;
+        lds.box[s][a] = a < 3 ? frames[s].lo[a] : frames[s].hi[a - 3];
+    }
+}
 // `g2` = the wave's first tile (its 64 rows are tiles g2 and g2 + 1: lanes 0-31 and 32-63).
 __device__ __forceinline__ void block_cull(CullLds &lds, const int g2, double (&lo)[3], double (&hi)[3], double ub,
                                            const SplitFrame *__restrict__ frames, const int nsplits, const GroupLists &gl,
@@ -111,20 +124,32 @@ __device__ __forceinline__ void block_cull(CullLds &lds, const int g2, double (&
         const int oany = __shfl_xor((int)any, 32, 64);
         aany = upper ? (oany != 0) : any, bany = upper ? any : (oany != 0);
     }
-    auto reach = [&](const int s, const double (&l)[3], const double (&h)[3], const double u) -> bool {
-        double g2s = 0.0;
+    const bool staged = nsplits <= kCullLdsBoxes;
+    // both tiles against split s -> bit 0: tile A within reach, bit 1: tile B
+    auto reach2 = [&](const int s) -> unsigned {
+        double sl[3], sh[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double g1 = l[a] - frames[s].hi[a], g3 = frames[s].lo[a] - h[a];
-            const double gg = g1 > g3 ? g1 : g3;
-            g2s += gg > 0.0 ? gg * gg : 0.0;
+            sl[a] = staged ? lds.box[s][a] : frames[s].lo[a];
+            sh[a] = staged ? lds.box[s][3 + a] : frames[s].hi[a];
         }
-        return !(g2s * (1.0 - 1e-12) > u * (1.0 + 1e-12));
+        double ga = 0.0, gb = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double a1 = alo[a] - sh[a], a3 = sl[a] - ahi[a], b1 = blo[a] - sh[a], b3 = sl[a] - bhi[a];
+            const double xa = a1 > a3 ? a1 : a3, xb = b1 > b3 ? b1 : b3;
+            ga += xa > 0.0 ? xa * xa : 0.0;
+            gb += xb > 0.0 ? xb * xb : 0.0;
+        }
+        const bool ra = aany & !(ga * (1.0 - 1e-12) > aub * (1.0 + 1e-12)), rb = bany & !(gb * (1.0 - 1e-12) > bub * (1.0 + 1e-12));
+        return (unsigned)ra | ((unsigned)rb << 1);
     };
-    __syncthreads(); // counters cleared
+    __syncthreads(); // counters cleared, boxes staged
+    unsigned first_bits = 0u; // the lane's own split of the first round, kept for the placement below
     for (int s = lane; s < nsplits; s += 64) {
-        const unsigned c = (unsigned)(aany && reach(s, alo, ahi, aub)) + (unsigned)(bany && reach(s, blo, bhi, bub));
-        if (c) atomicAdd(&lds.cnt[s], c);
+        const unsigned bits = reach2(s);
+        if (s == lane) first_bits = bits;
+        if (bits) atomicAdd(&lds.cnt[s], (bits & 1u) + (bits >> 1));
     }
     __syncthreads(); // counted
     for (int s = threadIdx.x; s < nsplits; s += blockDim.x) {
@@ -133,12 +158,12 @@ __device__ __forceinline__ void block_cull(CullLds &lds, const int g2, double (&
     }
     __syncthreads(); // runs reserved: cnt[] now holds each run's cursor
     for (int s = lane; s < nsplits; s += 64) {
-        const bool ra = aany && reach(s, alo, ahi, aub), rb = bany && reach(s, blo, bhi, bub);
-        if (ra || rb) {
-            const unsigned pos = atomicAdd(&lds.cnt[s], (unsigned)ra + (unsigned)rb);
+        const unsigned bits = s == lane ? first_bits : reach2(s);
+        if (bits) {
+            const unsigned pos = atomicAdd(&lds.cnt[s], (bits & 1u) + (bits >> 1));
             unsigned *dst = gl.items + (size_t)s * gl.cap + pos;
-            if (ra) dst[0] = (unsigned)g2;
-            if (rb) dst[ra ? 1 : 0] = (unsigned)g2 + 1u;
+            if (bits & 1u) dst[0] = (unsigned)g2;
+            if (bits & 2u) dst[bits & 1u] = (unsigned)g2 + 1u;
         }
     }
 }
@@ -187,6 +212,7 @@ __global__ __launch_bounds__(kPreThreads) void k_nn_prebound1(const double *__re
                                                       const GroupLists gl)
 {
     __shared__ CullLds cl;
+    if (gl.cnt) cull_stage_boxes(cl, frames, nsplits);
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kPreThreads + threadIdx.x;
     const bool valid = i < n;
@@ -248,6 +274,7 @@ __global__ __launch_bounds__(256) void k_transform_cull(const double *in, const 
 {
     __shared__ CullLds cl;
     if (honour_done && st->done) return;
+    if (gl.cnt && rb.ub) cull_stage_boxes(cl, frames, nsplits);
     const double *T = which ? st->total : st->delta;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -299,6 +326,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform_cull(
         }
     };
     load_row(i0);
+    cull_stage_boxes(cl, frames, nsplits);
     state_copy(&ls, sin);
     finish_sums(partials, nblocks, n_local, &sums);
     __syncthreads();
@@ -357,6 +385,7 @@ __global__ __launch_bounds__(256) void k_step_transform_cull(const double *in, d
         }
     };
     load_row(i0);
+    cull_stage_boxes(cl, frames, nsplits);
     state_copy(&ls, sin);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -401,6 +430,7 @@ __global__ __launch_bounds__(1024) void k_knn_group_cull(const double *__restric
                                                         int nsplits, const GroupLists gl)
 {
     __shared__ CullLds cl;
+    cull_stage_boxes(cl, frames, nsplits);
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 16 + (threadIdx.x >> 6); // the wave's 64 rows: groups 2 w and 2 w + 1
     const int local = w * 64 + lane;
