@@ -1295,7 +1295,11 @@ int align_device(icpmi_ctx *ctx, const double *d_src, int64_t n_src64, const dou
     // (not where ICPMI_SMALL=0 puts the general kernels in the small-cloud kernel's place: there they keep its order of rows,
     // hence its bits)
     const bool small_regime = !sharded_run && n <= small_max_queries() && ctx->nn_splits <= small_max_splits();
-    const bool sorted_rows_loop = fused && !pruned && !small && !small_regime && n >= 4096 && resolve_waves(n) != -32;
+    // (and only against targets of more than a dozen splits: at 10 splits -- 18k x 20k points, six iterations -- the rows' sort is
+    // 55 us of a 0.45 ms registration whose coarse pass is 5 us; profiles/r4_final/c2_20k/timeline.txt)
+    constexpr int kSortRowsFromSplits = 12;
+    const bool sorted_rows_loop = fused && !pruned && !small && !small_regime && n >= 4096 && ctx->nn_splits > kSortRowsFromSplits &&
+                                  resolve_waves(n) != -32;
     size_t sort_bytes = 0;
     if (pruned || sorted_rows_loop) {
         HIP_TRY(ctx, sort_pairs_u32(nullptr, &sort_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned)n, s));

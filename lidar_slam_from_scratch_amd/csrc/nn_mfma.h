@@ -196,12 +196,23 @@ __global__ __launch_bounds__(1024) void k_bbox_single(const double *__restrict__
                                                       unsigned long long *__restrict__ clear3)
 {
     double lo[3] = {1.7e308, 1.7e308, 1.7e308}, hi[3] = {-1.7e308, -1.7e308, -1.7e308};
-    for (int i = threadIdx.x; i < m; i += 1024) {
-        const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-        if (finite_only && !finite3(x, y, z)) continue;
-        lo[0] = x < lo[0] ? x : lo[0], hi[0] = x > hi[0] ? x : hi[0];
-        lo[1] = y < lo[1] ? y : lo[1], hi[1] = y > hi[1] ? y : hi[1];
-        lo[2] = z < lo[2] ? z : lo[2], hi[2] = z > hi[2] ? z : hi[2];
+    // eight points per thread and round, their loads in flight together (as one point per trip the kernel was a chain of
+    // m / 1024 memory round trips: 13.9 us for 20k points where the two-launch form took 9)
+    constexpr int U = 8;
+    for (int base = threadIdx.x; base < m; base += 1024 * U) {
+        double x[U], y[U], z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * 1024, ic = i < m ? i : m - 1; // (clamped: the last point twice changes no box)
+            x[u] = pts[3 * ic], y[u] = pts[3 * ic + 1], z[u] = pts[3 * ic + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = !finite_only || finite3(x[u], y[u], z[u]);
+            lo[0] = ok && x[u] < lo[0] ? x[u] : lo[0], hi[0] = ok && x[u] > hi[0] ? x[u] : hi[0];
+            lo[1] = ok && y[u] < lo[1] ? y[u] : lo[1], hi[1] = ok && y[u] > hi[1] ? y[u] : hi[1];
+            lo[2] = ok && z[u] < lo[2] ? z[u] : lo[2], hi[2] = ok && z[u] > hi[2] ? z[u] : hi[2];
+        }
     }
     __shared__ double red[16][6];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

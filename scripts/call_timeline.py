@@ -14,9 +14,11 @@ f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "").replace("icpmi::", "")
 # the calls: a call of this library starts with the target's bounding box (k_bbox_partial) after a stretch without launches
-starts = [i for i, r in enumerate(rows) if "k_bbox_partial" in r["Kernel_Name"] and
+starts = [i for i, r in enumerate(rows) if ("k_bbox_partial" in r["Kernel_Name"] or "k_bbox_single" in r["Kernel_Name"]) and
           (i == 0 or int(r["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"]) > 20000 or "k_finish_step" in rows[i - 1]["Kernel_Name"]
-           or "copyBuffer" in rows[i - 1]["Kernel_Name"])]
+           or "copyBuffer" in rows[i - 1]["Kernel_Name"] or "fillBuffer" in rows[i - 1]["Kernel_Name"])]
+# (the state's upload may sit between the previous call's copies and this call's first kernel)
+starts = [i for k, i in enumerate(starts) if k == 0 or i - starts[k - 1] > 8]
 i0 = starts[-1]
 call = rows[i0:]
 t0 = int(call[0]["Start_Timestamp"])

@@ -3,7 +3,8 @@
 # summaries are copied into profiles/r4_final/ by scripts/collect_profiles_r4.py (see profiles/README.md).
 # usage: scripts/final_profile_r4.sh a   bench lines, kernel stats of the same command, counter passes for both engines' dominant
 #                                        kernels, secondary workloads, the culled kernel's in-kernel stamps, C2 at 20k
-#        scripts/final_profile_r4.sh b   frame stream, small-cloud regime, A/B runs, engine thresholds, fuzz runs
+#        scripts/final_profile_r4.sh b   engine thresholds, offsets, frame stream, small-cloud A/B, batch
+#        scripts/final_profile_r4.sh c   the all-pairs kernel's in-kernel clock, the small-cloud regime under rocprofv3, fuzz runs
 cd "$GRAFT_REPO_ROOT"
 O="$GRAFT_REPO_ROOT/gpurun_out/final4"
 mkdir -p "$O"
@@ -32,6 +33,7 @@ python scripts/prof_summary.py "$O" > "$O/summary.txt" 2>&1
 echo done a
 exit 0
 fi
+if [ "$part" = "b" ]; then
 timeout -k 10 200 python scripts/engine_threshold.py > "$O/engine_threshold.json" 2> "$O/engine_threshold.err" || exit 1
 timeout -k 10 200 python scripts/offset_timing.py > "$O/offset_timing.json" 2> "$O/offset_timing.err" || exit 1
 # C5 at stream length: 200 synthetic frames as KITTI .bin, file -> pose, with the oracle loop beside it; the map side
@@ -39,8 +41,13 @@ timeout -k 10 600 python scripts/run_sequence.py --make-synthetic /tmp/drive200 
 timeout -k 10 600 python scripts/run_sequence.py --data_dir /tmp/drive200 --frames 0:200 --oracle --map > "$O/sequence_200_map.json" 2> "$O/sequence_200_map.err" || exit 1
 timeout -k 10 400 python scripts/ab_small.py > "$O/ab_small.json" 2> "$O/ab_small.err" || exit 1
 timeout -k 10 300 python scripts/batch_timing.py > "$O/batch_timing.json" 2> "$O/batch_timing.err" || exit 1
+echo done b
+exit 0
+fi
+# part c
 timeout -k 10 300 python scripts/coarse_clock.py 100000 3 > "$O/coarse_clock.json" 2> "$O/coarse_clock.err" || exit 1
 mkdir -p "$O/small"
+[ -d /tmp/drive200 ] || timeout -k 10 300 python scripts/run_sequence.py --make-synthetic /tmp/drive200 --frames 0:200 > /dev/null 2>&1 || exit 1
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/small/stats" -- python3 "$GRAFT_REPO_ROOT/scripts/run_sequence.py" --data_dir /tmp/drive200 --frames 0:40 > "$O/small/sequence_40_under_rocprof.json" 2> "$O/small/stats.err") || exit 1
 timeout -k 10 300 python scripts/fuzz_stopping.py 400 52000 > "$O/fuzz_stopping.txt" 2>&1 || exit 1
 timeout -k 10 500 python scripts/fuzz_engines.py 2000 410000 > "$O/fuzz_engines.txt" 2>&1 || exit 1
