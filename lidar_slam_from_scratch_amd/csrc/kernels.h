@@ -241,11 +241,12 @@ __device__ inline void finish_sums(const double *__restrict__ partials, int nblo
 // ceil(nblocks / kSumGroup) rows.  A kernel of its own, not a hand-off inside the resolve kernel: with the last workgroup
 // of a group adding the group's rows behind agent-scope fences the resolve took 170 us instead of 27 at C3 (a release
 // writes the XCD's L2 back, an acquire drops the CU's L1, once per workgroup and seven workgroups to a CU), and the
-// fence-free sc1 form is measured for one workgroup per CU only (MI355X_MICROARCH.md).  A launch boundary costs ~3 us: it
-// pays from a few thousand rows, not at C3's 1,563 (ICPMI_SUM_TREE_FROM moves the threshold; the sums' order of
-// additions differs on either side of it, inside every tolerance of the tests).
+// fence-free sc1 form is measured for one workgroup per CU only (MI355X_MICROARCH.md).  A launch boundary costs ~3 us and
+// the step kernel's sum of C3's 1,563 rows 6.7: measured at C3, default engine, 30 iterations, same box: 9,614 -> 9,810
+// iterations/s with the threshold at 1,024 rows (ICPMI_SUM_TREE_FROM moves it; the sums' order of additions differs on
+// either side of it, inside every tolerance of the tests).
 constexpr int kSumGroup = 16;
-constexpr int kSumTreeFrom = 4096;
+constexpr int kSumTreeFrom = 1024;
 __global__ __launch_bounds__(256) void k_sum_groups(const double *__restrict__ rows, int nblocks, double *__restrict__ rows2,
                                                     const IcpState *__restrict__ st)
 {
