@@ -1048,7 +1048,8 @@ def test_bounded_pass_gives_the_unbounded_pass_bits():
     bounded passes AND the culled engine's (nn_culled.h: the same passes on the (64-row group, split) pairs within
     reach; what AUTO runs on these targets) -- for both resolve layouts (16 rows per wave above 32,768 rows, one per quarter-wave below) and both coarse
     unit sizes: uniform clouds, a raw
-    LiDAR-like frame pair, a cloud full of exact ties, a source with NaN / infinite rows, a start so far off that the
+    LiDAR-like frame pair, a cloud full of exact ties, a source with NaN / infinite rows, a target with NaN / infinite points
+    (their keys sort to one corner: the first pass's window there holds no candidate), a start so far off that the
     bounds span the whole target (every row takes the exhaustive search behind the split boxes), and two ranks."""
     import json
     import subprocess
@@ -1071,6 +1072,8 @@ grid = rng.integers(-20, 20, (70000, 3)).astype(np.float64)
 cases["ties"] = (grid[:40000] + 0.25, grid, None, 5)
 s2 = s.copy(); s2[17] = np.nan; s2[40001, 1] = np.inf
 cases["nan_rows"] = (s2, t, None, 5)
+t2 = t.copy(); t2[11] = np.nan; t2[30001, 2] = np.inf; t2[59999, 0] = -np.inf   # targets nobody may be matched with (kdtree.hpp:125)
+cases["nan_targets"] = (s[:50000], t2, None, 4)
 T0 = synth.make_transform(np.array([0.3, -0.2, 0.25]), np.array([40.0, -25.0, 10.0]))
 cases["far_start"] = (s[:36000], t, T0, 4)
 out = {}

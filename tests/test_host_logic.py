@@ -59,3 +59,19 @@ def test_more_candidates_than_one_batch_takes():
     assert [r.match_frame for r in seq] == [r.match_frame for r in found]
     # fewer wanted than offered: stops after the third ACCEPTED one, as the reference does
     assert [r.match_frame for r in _run(_FakeBackend(accept), 3)] == [0, 2, 3]
+
+
+def test_cpu_baseline_is_pinned_and_a_median_of_three():
+    """bench.py's 1-thread CPU leg runs in a child process pinned to one core (sched_setaffinity before the
+    oracle is loaded), three times; the median and the three samples are reported.  (A small cloud here: the bench uses C3.)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.cpu_baseline_pinned(3000, 2, samples=3)
+    assert len(out["samples_it_per_s"]) == 3 and all(v > 0 for v in out["samples_it_per_s"])
+    assert out["value"] == sorted(out["samples_it_per_s"])[1]
+    assert out["pinned_cpu"] in os.sched_getaffinity(0) and out["affinity_seen_by_child"] == [out["pinned_cpu"]]
+    assert out["loops"] == 2
