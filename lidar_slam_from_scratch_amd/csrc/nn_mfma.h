@@ -740,7 +740,11 @@ __device__ __forceinline__ void coarse_unit_rows(uint4 *lds, const int q0, const
     if (wave & 1) __builtin_amdgcn_s_setprio(1);
 #endif
     // B operands: 2 chunks of 32 tiles through one 32 KiB LDS buffer
+#if defined(ICPMI_TIMING_B0) /* timing experiment only (WRONG results): every unit reads split 0's operands -- what L2 misses on them cost */
+    const uint4 *src = Bpack;
+#else
     const uint4 *src = Bpack + (size_t)s * (kSplitTiles * 64);
+#endif
 #pragma unroll 1
     for (int chunk = 0; chunk < kSplitTiles / kChunkTiles; ++chunk) {
         __syncthreads(); // A rows / previous chunk no longer needed
