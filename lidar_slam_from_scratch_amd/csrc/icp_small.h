@@ -78,13 +78,6 @@ __device__ __forceinline__ void small_merge(float &v1, float &v2, const float w1
 #endif
 constexpr int kSmallStamps = 12;
 
-// value of `v` in lane `l` (wave-uniform l): two v_readlane_b32, the result lives in scalar registers
-__device__ __forceinline__ double readlane_f64(double v, int l)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
 __global__ __launch_bounds__(kSmallThreads) void k_icp_small(
     const double *in, double *cur, int n, const IcpState *__restrict__ st, int which,
     const uint4 *__restrict__ Bpack, const SplitFrame *__restrict__ frames, int splits,
@@ -196,7 +189,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_icp_small(
             const unsigned col = (__float_as_uint(v1) & 15u) | ((unsigned)half << 4);
             v1 = tag_low5(min_raw(__uint_as_float(__float_as_uint(v1) & 0xFFFFFFE0u) + pn, kBig), col);
             v2 = min_raw(__uint_as_float(__float_as_uint(v2) & 0xFFFFFFE0u) + pn, kBig);
-            const float o1 = __shfl_xor(v1, 32, 64), o2 = __shfl_xor(v2, 32, 64);
+            const float o1 = lane_xor<32>(v1), o2 = lane_xor<32>(v2);
             const float hi = __builtin_fmaxf(v1, o1);
             v1 = __builtin_fminf(v1, o1);
             v2 = min3f(hi, v2, o2);
@@ -241,15 +234,16 @@ __global__ __launch_bounds__(kSmallThreads) void k_icp_small(
     int bcol;
     {
         float best = v1;
-#pragma unroll
-        for (int xo = 1; xo < 16; xo <<= 1) {
-            const float ov = __shfl_xor(best, xo, 64);
-            const int os = __shfl_xor(bs, xo, 64);
-            if (ov < best || (ov == best && os < bs)) {
-                best = ov;
-                bs = os;
-            }
+#define ICPMI_STEP(S)                                                                     \
+        {                                                                                 \
+            const float ov = row16_partner<S>(best);                                      \
+            const int os = row16_partner<S>(bs);                                          \
+            const bool take = (ov < best) | ((ov == best) & (os < bs));                   \
+            best = take ? ov : best;                                                      \
+            bs = take ? os : bs;                                                          \
         }
+        ICPMI_STEP(0) ICPMI_STEP(1) ICPMI_STEP(2) ICPMI_STEP(3) // (device_math.h: DPP partners, no LDS trip)
+#undef ICPMI_STEP
         bcol = (int)(__float_as_uint(best) & 31u);
     }
 
@@ -283,15 +277,16 @@ __global__ __launch_bounds__(kSmallThreads) void k_icp_small(
     }
     double bd = ld;
     int bj = lj;
-#pragma unroll
-    for (int xo = 1; xo < 16; xo <<= 1) {
-        const double od = __shfl_xor(bd, xo, 64);
-        const int oj = __shfl_xor(bj, xo, 64);
-        if (od < bd || (od == bd && oj < bj)) {
-            bd = od;
-            bj = oj;
-        }
+#define ICPMI_STEP(S)                                                                 \
+    {                                                                                 \
+        const double od = row16_partner<S>(bd);                                       \
+        const int oj = row16_partner<S>(bj);                                          \
+        const bool take = (od < bd) | ((od == bd) & (oj < bj));                       \
+        bd = take ? od : bd;                                                          \
+        bj = take ? oj : bj;                                                          \
     }
+    ICPMI_STEP(0) ICPMI_STEP(1) ICPMI_STEP(2) ICPMI_STEP(3)
+#undef ICPMI_STEP
     ICPMI_SMALL_STAMP(4); // slots scanned
 
     // certificate: every split's record against its bound (resolve_certify without the first filter:

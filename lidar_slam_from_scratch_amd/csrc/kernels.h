@@ -308,6 +308,60 @@ __device__ inline void step_update(IcpState *st, double *history, int final_pass
     st->prev_error = error;              // icp.hpp:231
 }
 
+// step_update by the workgroup's first WAVE (all 64 lanes call it, `st` in LDS): the bookkeeping is lane 0's, the solve
+// and the 4x4 product are spread over the lanes (ldlt6_solve_wave, mul44_wave), Rodrigues is computed by every lane alike.
+// Same operations on every value as step_update -> same bits; ~2.6 instead of 4.7 us between the sums and the moved rows
+// of every iteration (scripts/micro/step_clocks.hip).
+__device__ inline void step_update_wave(IcpState *st, double *history, int final_pass, int lane)
+{
+    const bool l0 = lane == 0;
+    if (st->done) {
+        if (l0 && final_pass && !st->finalized) {
+            st->final_error = st->last_error;
+            if (history && st->hist_len < st->max_hist) history[st->hist_len] = st->last_error;
+            st->hist_len += 1;
+            st->finalized = 1;
+        }
+        return;
+    }
+    const double error = __dsqrt_rn(st->sums[27] / st->sums[28]);
+    const double prev_error = st->prev_error;
+    const bool stop = error < st->min_error || fabs(prev_error - error) < st->tolerance; // icp.hpp:210-213, 214-217
+    const int hist_len = st->hist_len, max_hist = st->max_hist;
+    __builtin_amdgcn_wave_barrier();
+    if (l0) {
+        if (history && hist_len < max_hist) history[hist_len] = error;
+        st->hist_len = hist_len + 1;
+        st->last_error = error;
+        if (final_pass) {
+            st->final_error = error;
+            st->done = 1;
+        } else {
+            st->loops += 1;
+            if (stop) { // (the post-loop entry is made now: see step_update)
+                st->converged = 1;
+                st->done = 1;
+                st->final_error = error;
+                if (history && hist_len + 1 < max_hist) history[hist_len + 1] = error;
+                st->hist_len = hist_len + 2;
+                st->finalized = 1;
+            } else {
+                st->prev_error = error; // icp.hpp:231
+            }
+        }
+    }
+    if (final_pass || stop) return;
+    double x[6], T[16];
+    ldlt6_solve_wave(st->sums, x, lane); // icp.hpp:120
+    twist_to_transform(x, T);            // icp.hpp:123-143
+    if (l0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st->delta[e] = T[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    mul44_wave(st->delta, st->total, st->total, lane); // icp.hpp:229
+}
+
 // single GPU: final sum + step in one launch
 // `progress` (may be null) is one word of host-mapped memory per iteration slot: the device
 // publishes (iteration + 1) * 2 + done there, so the host can stop queueing iterations
@@ -342,9 +396,9 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step(const double *__
     __syncthreads();
     if (!ls.done && threadIdx.x < kNumSums) ls.sums[threadIdx.x] = sums.sums[threadIdx.x];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        step_update(&ls, history, final_pass);
-        publish_progress(progress, ticket, ls.done);
+    if (threadIdx.x < 64) {
+        step_update_wave(&ls, history, final_pass, threadIdx.x);
+        if (threadIdx.x == 0) publish_progress(progress, ticket, ls.done);
     }
     __syncthreads();
     state_copy(st, &ls);
@@ -376,15 +430,16 @@ __global__ __launch_bounds__(64) void k_step(IcpState *st, double *history, int 
     __shared__ IcpState ls;
     state_copy(&ls, st);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) { // the first wave (step_update_wave)
         const double ndone = ls.sums[kDoneSlot];
         const bool all = ndone == (double)n_ranks, some = ndone > 0.0 && !all;
-        if (some) {
+        if (some && threadIdx.x == 0) {
             ls.error = 1;
             ls.done = 1;
         }
-        step_update(&ls, history, final_pass);
-        publish_progress(progress, ticket, all || some);
+        __builtin_amdgcn_wave_barrier();
+        step_update_wave(&ls, history, final_pass, threadIdx.x);
+        if (threadIdx.x == 0) publish_progress(progress, ticket, all || some);
     }
     __syncthreads();
     state_copy(st, &ls);
@@ -484,15 +539,16 @@ __global__ __launch_bounds__(256) void k_step_transform(const double *in, double
     rows.load(in, rb, i0, stride, n);
     state_copy(&ls, sin);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) { // the first wave (step_update_wave)
         const double ndone = ls.sums[kDoneSlot];
         const bool all = ndone == (double)n_ranks, some = ndone > 0.0 && !all;
-        if (some) {
+        if (some && threadIdx.x == 0) {
             ls.error = 1;
             ls.done = 1;
         }
-        step_update(&ls, blockIdx.x == 0 ? history : nullptr, 0);
-        if (blockIdx.x == 0) publish_progress(progress, ticket, all || some);
+        __builtin_amdgcn_wave_barrier();
+        step_update_wave(&ls, blockIdx.x == 0 ? history : nullptr, 0, threadIdx.x);
+        if (threadIdx.x == 0 && blockIdx.x == 0) publish_progress(progress, ticket, all || some);
     }
     __syncthreads();
     if (blockIdx.x == 0) state_copy(sout, &ls);
@@ -525,9 +581,9 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform(
     __syncthreads();
     if (!ls.done && threadIdx.x < kNumSums) ls.sums[threadIdx.x] = sums.sums[threadIdx.x];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        step_update(&ls, blockIdx.x == 0 ? history : nullptr, 0);
-        if (blockIdx.x == 0) publish_progress(progress, ticket, ls.done);
+    if (threadIdx.x < 64) { // the first wave (step_update_wave)
+        step_update_wave(&ls, blockIdx.x == 0 ? history : nullptr, 0, threadIdx.x);
+        if (threadIdx.x == 0 && blockIdx.x == 0) publish_progress(progress, ticket, ls.done);
     }
     __syncthreads();
     if (blockIdx.x == 0) state_copy(sout, &ls);

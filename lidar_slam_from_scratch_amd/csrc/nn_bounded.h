@@ -70,10 +70,11 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     const uint2 w = *reinterpret_cast<const uint2 *>(ent_row + (size_t)ic * kNnEntCap + 2 * sub);
     const unsigned w0 = (look && 2 * sub < cnt) ? w.x : 0u, w1 = (look && 2 * sub + 1 < cnt) ? w.y : 0u;
     const int mine = __popc(w0 & 0xFFFFu) + __popc(w1 & 0xFFFFu);
-    int incl = mine;
-    { const int o = __shfl_up(incl, 16, 64); incl += sub >= 1 ? o : 0; }
-    { const int o = __shfl_up(incl, 32, 64); incl += sub >= 2 ? o : 0; }
-    const int nsl = __shfl(incl, 48 + ql, 64); // listed slots of query ql (every sub-lane of the query knows it)
+    // prefix over the query's four sub-lanes (one in each row of 16 lanes) and the total, by two row exchanges
+    const int pair = mine + lane_xor<16>(mine);                   // this sub-lane's pair of rows
+    const int other = lane_xor<32>(pair);                          // the other pair
+    const int incl = ((sub & 1) ? pair : mine) + ((sub & 2) ? other : 0);
+    const int nsl = pair + other; // listed slots of query ql (every sub-lane of the query knows it)
     auto word_base = [](unsigned word) -> int { return (int)(word >> 17) * kCols + (int)((word >> 16) & 1u) * 16; };
     const int first_slot = word_base(w0) + ((w0 & 0xFFFFu) ? __ffs((int)(w0 & 0xFFFFu)) - 1 : 0); // (valid in sub-lane 0)
     // More words or slots than fit -> the exhaustive search below.  So does a finite row that lists NOTHING: with a previous
@@ -143,14 +144,16 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-#pragma unroll
-        for (int x = 1; x < 16; x <<= 1) {
-            const double od = __shfl_xor(d[r], x, 64);
-            const int oj = __shfl_xor(jo[r], x, 64);
-            const bool take = (od < d[r]) | ((od == d[r]) & (oj < jo[r]));
-            d[r] = take ? od : d[r];
-            jo[r] = take ? oj : jo[r];
+#define ICPMI_STEP(S)                                                                     \
+        {                                                                                 \
+            const double od = row16_partner<S>(d[r]);                                     \
+            const int oj = row16_partner<S>(jo[r]);                                       \
+            const bool take = (od < d[r]) | ((od == d[r]) & (oj < jo[r]));                \
+            d[r] = take ? od : d[r];                                                      \
+            jo[r] = take ? oj : jo[r];                                                    \
         }
+        ICPMI_STEP(0) ICPMI_STEP(1) ICPMI_STEP(2) ICPMI_STEP(3)
+#undef ICPMI_STEP
     }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -245,13 +248,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4_bounded(
     const int cnt = cnt_row[ic];
     const unsigned w = (look && ql < cnt && ql < kNnEntCap) ? ent_row[(size_t)ic * kNnEntCap + ql] : 0u;
     const int mine = __popc(w & 0xFFFFu);
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < kNnEntCap; off <<= 1) {
-        const int o = __shfl_up(incl, off, 64);
-        incl += ql >= off ? o : 0;
-    }
-    const int nsl = __shfl(incl, quarter * 16 + kNnEntCap - 1, 64);
+    const int incl = row16_scan_incl(mine); // (lanes 8-15 of the quarter hold no word: their count is 0)
+    int nsl = mine;
+    nsl += row16_partner<0>(nsl), nsl += row16_partner<1>(nsl), nsl += row16_partner<2>(nsl), nsl += row16_partner<3>(nsl);
     auto word_base = [](unsigned word) -> int { return (int)(word >> 17) * kCols + (int)((word >> 16) & 1u) * 16; };
     const unsigned w0 = (unsigned)__shfl((int)w, quarter * 16, 64);
     const int first_slot = word_base(w0) + ((w0 & 0xFFFFu) ? __ffs((int)(w0 & 0xFFFFu)) - 1 : 0);
@@ -285,14 +284,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4_bounded(
         __builtin_amdgcn_wave_barrier();
         for (int t = 1; __ballot(t < ns) != 0ull; ++t) scan_slot(t < ns ? flist[wave][quarter][t] : 0, t < ns);
     }
-#pragma unroll
-    for (int x = 1; x < 16; x <<= 1) {
-        const double od = __shfl_xor(d, x, 64);
-        const int oj = __shfl_xor(jo, x, 64);
-        const bool take = (od < d) | ((od == d) & (oj < jo));
-        d = take ? od : d;
-        jo = take ? oj : jo;
+#define ICPMI_STEP(S)                                                                 \
+    {                                                                                 \
+        const double od = row16_partner<S>(d);                                        \
+        const int oj = row16_partner<S>(jo);                                          \
+        const bool take = (od < d) | ((od == d) & (oj < jo));                         \
+        d = take ? od : d;                                                            \
+        jo = take ? oj : jo;                                                          \
     }
+    ICPMI_STEP(0) ICPMI_STEP(1) ICPMI_STEP(2) ICPMI_STEP(3)
+#undef ICPMI_STEP
     {
         const bool take = look & ((d < bd) | ((d == bd) & (jo < bj)));
         bd = take ? d : bd;

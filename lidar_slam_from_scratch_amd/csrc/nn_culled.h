@@ -77,17 +77,19 @@ __device__ __forceinline__ void block_cull(CullLds &lds, const int g2, double (&
     __syncthreads(); // (a workgroup with several rounds of rows: the previous round's cursors are no longer in use)
     for (int s = threadIdx.x; s < nsplits; s += blockDim.x) lds.cnt[s] = 0u;
     // box and bound of each HALF of the wave (one tile each): five exchange steps inside the halves
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double l2 = __shfl_xor(lo[a], off, 64), h2 = __shfl_xor(hi[a], off, 64);
-            lo[a] = l2 < lo[a] ? l2 : lo[a];
-            hi[a] = h2 > hi[a] ? h2 : hi[a];
-        }
-        const double u2 = __shfl_xor(ub, off, 64);
-        ub = u2 > ub ? u2 : ub;
+    // (lane_xor: DPP / v_permlane16_swap moves, device_math.h -- as __shfl_xor these were 70 LDS crossbar trips)
+#define ICPMI_STEP(X)                                                                     \
+    {                                                                                     \
+        _Pragma("unroll") for (int a = 0; a < 3; ++a) {                                   \
+            const double l2 = lane_xor<X>(lo[a]), h2 = lane_xor<X>(hi[a]);                \
+            lo[a] = l2 < lo[a] ? l2 : lo[a];                                              \
+            hi[a] = h2 > hi[a] ? h2 : hi[a];                                              \
+        }                                                                                 \
+        const double u2 = lane_xor<X>(ub);                                                \
+        ub = u2 > ub ? u2 : ub;                                                           \
     }
+    ICPMI_STEP(16) ICPMI_STEP(8) ICPMI_STEP(4) ICPMI_STEP(2) ICPMI_STEP(1)
+#undef ICPMI_STEP
     const bool any = lo[0] <= hi[0]; // a finite row in this half's tile
     if (__ballot(any && !(ub < 1.0e300)) != 0ull) { // (rare: a tile without any bound)
         double far2 = __builtin_inf();
@@ -101,11 +103,9 @@ __device__ __forceinline__ void block_cull(CullLds &lds, const int g2, double (&
             }
             far2 = f2 < far2 ? f2 : far2;
         }
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-            const double o = __shfl_xor(far2, off, 64);
-            far2 = o < far2 ? o : far2;
-        }
+#define ICPMI_STEP(X) { const double o = lane_xor<X>(far2); far2 = o < far2 ? o : far2; }
+        ICPMI_STEP(16) ICPMI_STEP(8) ICPMI_STEP(4) ICPMI_STEP(2) ICPMI_STEP(1)
+#undef ICPMI_STEP
         if (!(ub < 1.0e300)) ub = far2 * (1.0 + 1e-12);
     }
     // every lane gets both tiles' boxes: A = lanes 0-31's, B = lanes 32-63's
@@ -115,13 +115,13 @@ __device__ __forceinline__ void block_cull(CullLds &lds, const int g2, double (&
         const bool upper = lane >= 32;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double ol = __shfl_xor(lo[a], 32, 64), oh = __shfl_xor(hi[a], 32, 64);
+            const double ol = lane_xor<32>(lo[a]), oh = lane_xor<32>(hi[a]);
             alo[a] = upper ? ol : lo[a], ahi[a] = upper ? oh : hi[a];
             blo[a] = upper ? lo[a] : ol, bhi[a] = upper ? hi[a] : oh;
         }
-        const double ou = __shfl_xor(ub, 32, 64);
+        const double ou = lane_xor<32>(ub);
         aub = upper ? ou : ub, bub = upper ? ub : ou;
-        const int oany = __shfl_xor((int)any, 32, 64);
+        const int oany = lane_xor<32>((int)any);
         aany = upper ? (oany != 0) : any, bany = upper ? any : (oany != 0);
     }
     const bool staged = nsplits <= kCullLdsBoxes;
@@ -332,9 +332,9 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform_cull(
     __syncthreads();
     if (!ls.done && threadIdx.x < kNumSums) ls.sums[threadIdx.x] = sums.sums[threadIdx.x];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        step_update(&ls, blockIdx.x == 0 ? history : nullptr, 0);
-        if (blockIdx.x == 0) publish_progress(progress, ticket, ls.done);
+    if (threadIdx.x < 64) { // the first wave (step_update_wave)
+        step_update_wave(&ls, blockIdx.x == 0 ? history : nullptr, 0, threadIdx.x);
+        if (threadIdx.x == 0 && blockIdx.x == 0) publish_progress(progress, ticket, ls.done);
     }
     __syncthreads();
     if (blockIdx.x == 0) state_copy(sout, &ls);
@@ -388,15 +388,16 @@ __global__ __launch_bounds__(256) void k_step_transform_cull(const double *in, d
     cull_stage_boxes(cl, frames, nsplits);
     state_copy(&ls, sin);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) { // the first wave (step_update_wave)
         const double ndone = ls.sums[kDoneSlot];
         const bool all = ndone == (double)n_ranks, some = ndone > 0.0 && !all;
-        if (some) {
+        if (some && threadIdx.x == 0) {
             ls.error = 1;
             ls.done = 1;
         }
-        step_update(&ls, blockIdx.x == 0 ? history : nullptr, 0);
-        if (blockIdx.x == 0) publish_progress(progress, ticket, all || some);
+        __builtin_amdgcn_wave_barrier();
+        step_update_wave(&ls, blockIdx.x == 0 ? history : nullptr, 0, threadIdx.x);
+        if (threadIdx.x == 0 && blockIdx.x == 0) publish_progress(progress, ticket, all || some);
     }
     __syncthreads();
     if (blockIdx.x == 0) state_copy(sout, &ls);
@@ -487,18 +488,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
             const int s = s0 + lane;
             const unsigned c = s < nsplits ? cnt[s] : 0u;
             const unsigned ch = (c + 2 * WAVES - 1) / (2 * WAVES);
-            unsigned inc = ch, tot = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned o = __shfl_up(inc, off, 64);
-                inc += lane >= off ? o : 0u;
-                tot += __shfl_xor(tot, off, 64);
-            }
+            const unsigned inc = wave_scan_incl(ch);
+            const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)wave_scan_incl(c), 63);
             if (s < nsplits) {
                 pre[s] = run + inc - ch;
                 lcnt[s] = c;
             }
-            run += __shfl(inc, 63, 64);
+            run += (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
             listed += tot;
         }
         if (lane == 0) {

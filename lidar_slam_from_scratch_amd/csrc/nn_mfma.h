@@ -664,7 +664,7 @@ __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const
             // still covers, so that the resolve falls back to exhaustive scans instead of missing slots
             v1 = tag_low5(min_raw(__uint_as_float(__float_as_uint(v1) & 0xFFFFFFE0u) + pnq, kBig), col);
             v2 = min_raw(__uint_as_float(__float_as_uint(v2) & 0xFFFFFFE0u) + pnq, kBig);
-            const float o1 = __shfl_xor(v1, 32, 64), o2 = __shfl_xor(v2, 32, 64);
+            const float o1 = lane_xor<32>(v1), o2 = lane_xor<32>(v2);
             const float hi = __builtin_fmaxf(v1, o1);
             v1 = __builtin_fminf(v1, o1);
             v2 = min3f(hi, v2, o2);

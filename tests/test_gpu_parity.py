@@ -11,6 +11,7 @@ import pytest
 from lidar_slam_from_scratch_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-4   # north_star tolerance
 HIST_TOL = 1e-9
@@ -1155,3 +1156,23 @@ def test_align_batch_is_the_sequential_calls(gpu_ctx):
         gpu_ctx.align_batch([q] * 9, [tgts[0]] * 9, cfg)                  # more than ICPMI_MAX_BATCH
     again = gpu_ctx.align(q, tgts[2], cfg)
     assert tuple(again[0].transformation) == tuple(alone[2][0].transformation)
+
+
+def test_wave_step_gives_the_one_lane_step_bits(tmp_path):
+    """The pose update of every iteration (6x6 LDLT solve, Rodrigues, 4x4 product: icp.hpp:120-143, 229) is done by a
+    whole wave since round 4 (device_math.h ldlt6_solve_wave: the pivot order from the input diagonal, one lane
+    permutation, a column per step; mul44_wave).  The one-lane form it replaced restates the oracle's operation order
+    statement by statement and stays in the header: scripts/micro/step_clocks.hip runs both on 60,000 systems -- well
+    conditioned, rank-deficient (one plane, normals in a plane, no lever arm), tie-heavy, small-integer indefinite, all
+    zero, NaN -- and compares solution, step transform and accumulated transform bit for bit (two NaNs are equal); it
+    also bounds sincos_step against the device library's sin / cos (<= 2 ulp; measured 1.00 / 0.71)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = tmp_path / "step_clocks"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-I",
+                           os.path.join(ROOT, "lidar_slam_from_scratch_amd", "csrc"),
+                           os.path.join(ROOT, "scripts", "micro", "step_clocks.hip"), "-o", str(exe)], stderr=subprocess.DEVNULL)
+    out = subprocess.run([str(exe), "64", "2000", "60000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "60000 systems: 0 differ" in out.stdout, out.stdout[-2000:]
