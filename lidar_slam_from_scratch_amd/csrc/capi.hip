@@ -513,7 +513,8 @@ int engine_for(const icpmi_ctx *ctx, int m, int n_hint)
         if (engine == ICPMI_SEARCH_MFMA_BF16 && splits > auto_culled_from_splits() && auto_culled_enabled()) engine = ICPMI_SEARCH_MFMA_PRUNED;
     }
     // (the culled coarse kernel keeps running sums over the splits in LDS: beyond kCullMaxSplits -- 6.3M targets -- all pairs)
-    if (engine == ICPMI_SEARCH_MFMA_PRUNED && splits > kCullMaxSplits) engine = ICPMI_SEARCH_MFMA_BF16;
+    // (and the length of a split's list in 20 bits: fewer than 2^20 tiles of 32 rows)
+    if (engine == ICPMI_SEARCH_MFMA_PRUNED && (splits > kCullMaxSplits || n_hint >= kCullMaxRows)) engine = ICPMI_SEARCH_MFMA_BF16;
     return engine;
 }
 

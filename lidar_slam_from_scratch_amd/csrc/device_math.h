@@ -89,6 +89,19 @@ template <int X> __device__ __forceinline__ double lane_xor(double v)
     return __hiloint2double(lane_xor<X>(__double2hiint(v)), lane_xor<X>(__double2loint(v)));
 }
 
+// lane_xor with the distance as an argument that is a constant after unrolling (the steps of a bitonic sort)
+template <typename T> __device__ __forceinline__ T lane_xor_n(T v, int x)
+{
+    switch (x) {
+    case 1: return lane_xor<1>(v);
+    case 2: return lane_xor<2>(v);
+    case 4: return lane_xor<4>(v);
+    case 8: return lane_xor<8>(v);
+    case 16: return lane_xor<16>(v);
+    default: return lane_xor<32>(v);
+    }
+}
+
 // inclusive prefix sum over the 64 lanes of a wave, six DPP additions (row shifts by 1, 2, 4, 8 with zero fill, then lane
 // 15 of each row to the next row's lanes -- rows 1 and 3 --, then lane 31 to rows 2 and 3): no LDS crossbar trip
 __device__ __forceinline__ unsigned wave_scan_incl(unsigned v)

@@ -38,7 +38,7 @@ __device__ __forceinline__ float half_sort_asc(float v, int hl)
     for (int k = 2; k <= 32; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const float o = __shfl_xor(v, j, 64);
+            const float o = lane_xor_n(v, j);
             const bool up = (hl & k) == 0, lower = (hl & j) == 0;
             const float mn = o < v ? o : v, mx = o < v ? v : o;
             v = (lower == up) ? mn : mx;

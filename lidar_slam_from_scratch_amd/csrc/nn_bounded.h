@@ -113,6 +113,8 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const int src = quarter * ROUNDS + r; // the query this quarter scans in round r (a lane with sub == 0)
+        // (measured and dropped: the coordinates by a load of their own instead of six LDS crossbar trips -- twelve more
+        // vector-memory instructions per lane in a kernel that waits on memory: 22.6 -> 23.8 us at C3, same box)
         qx[r] = __shfl(px, src, 64), qy[r] = __shfl(py, src, 64), qz[r] = __shfl(pz, src, 64);
         ns[r] = __shfl(nsl_eff, src, 64);
         d[r] = kMax;
@@ -155,25 +157,33 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
         ICPMI_STEP(0) ICPMI_STEP(1) ICPMI_STEP(2) ICPMI_STEP(3)
 #undef ICPMI_STEP
     }
+    // Query ql was scanned by quarter ql / ROUNDS in round ql % ROUNDS, and every lane of that quarter holds the result: the
+    // query's sub-lane IN that quarter is its OWNER from here on (incumbent, exhaustive search, terms) -- no exchange
+    // between the rows of 16 lanes (as a gather from the scanning quarter this was twelve LDS crossbar trips per wave)
+    const bool own = sub == ql / ROUNDS;
+    {
+        double rd = d[0];
+        int rj = jo[0];
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        // query ql was scanned by quarter ql / ROUNDS in round ql % ROUNDS
-        const double rd = __shfl(d[r], (ql / ROUNDS) * 16, 64);
-        const int rj = __shfl(jo[r], (ql / ROUNDS) * 16, 64);
-        const bool take = ((ql % ROUNDS) == r) & look & ((rd < bd) | ((rd == bd) & (rj < bj)));
+        for (int r = 1; r < ROUNDS; ++r) {
+            const bool sel = (ql % ROUNDS) == r;
+            rd = sel ? d[r] : rd;
+            rj = sel ? jo[r] : rj;
+        }
+        const bool take = own & look & ((rd < bd) | ((rd == bd) & (rj < bj)));
         bd = take ? rd : bd;
         bj = take ? rj : bj;
     }
 
 #if defined(ICPMI_NNB_STOP) && ICPMI_NNB_STOP == 3
-    if (nsl_eff >= 0) { if (valid && sub == 0) idx[i] = bj + (int)bd; return; }
+    if (nsl_eff >= 0) { if (valid && own) idx[i] = bj + (int)bd; return; }
 #endif
     // rows whose list did not fit: every split whose bounding box is within the incumbent's distance, its slots culled
     // by their boxes (scan_split), nearest-first is not needed for correctness -- the radius only shrinks
     unsigned extra_splits = 0;
-    unsigned long long pend = __ballot(over && sub == 0);
+    unsigned long long pend = __ballot(over && own);
     while (pend) { // rare; wave-uniform loop
-        const int L = __ffsll((long long)pend) - 1;
+        const int L = __ffsll((long long)pend) - 1; // (the query's owner)
         pend &= pend - 1;
         const double qx = __shfl(px, L, 64), qy = __shfl(py, L, 64), qz = __shfl(pz, L, 64);
         double qd = __shfl(bd, L, 64);
@@ -208,10 +218,10 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     }
 
 #if defined(ICPMI_NNB_STOP) && ICPMI_NNB_STOP == 4
-    if (nsl_eff >= 0) { if (valid && sub == 0) idx[i] = bj + (int)bd; return; }
+    if (nsl_eff >= 0) { if (valid && own) idx[i] = bj + (int)bd; return; }
 #endif
-    const unsigned extra_slots = (sub == 0 && look && !over && nsl > 1) ? (unsigned)(nsl - 1) : 0u;
-    resolve_finish<Q>(lane, wave, ql, sub, i, valid, bd, bj, px, py, pz, m, idx, nullptr, counters, extra_slots, extra_splits,
+    const unsigned extra_slots = (own && look && !over && nsl > 1) ? (unsigned)(nsl - 1) : 0u;
+    resolve_finish<Q>(lane, wave, ql, own, i, valid, bd, bj, px, py, pz, m, idx, nullptr, counters, extra_slots, extra_splits,
                       tgt_orig, nrm, partials, -1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);
 }
 

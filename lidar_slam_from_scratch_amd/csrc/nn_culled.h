@@ -53,6 +53,7 @@ struct GroupLists {
 // ~7,400 pairs of a C3 pass queued up on 49 addresses: 150 returning atomics per address, one after the other in the L2 --
 // the kernel took 29.6 us against the 16.9 of the form without lists.)  Must be called by every wave of the workgroup
 // (four barriers); a wave without rows passes lo = +big, hi = -big.
+constexpr int kCullMaxRows = 1 << 25;                      // rows of a source (k_nn_coarse_groups keeps a list's length in 20 bits: tiles of 32 rows)
 constexpr int kCullLdsBoxes = 128; // targets of up to this many splits (262k points): the splits' boxes are staged in LDS
 struct CullLds {
     unsigned cnt[kCullMaxSplits];   // survivors of this workgroup per split, then the cursor inside its run
@@ -479,26 +480,48 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
 #endif
     __shared__ uint4 lds[CoarseLds<WAVES>::SCRATCH16];
     extern __shared__ unsigned dyn_lds[];
-    unsigned *pre = dyn_lds, *lcnt = dyn_lds + nsplits + 1;
+    // pre[s]: FULL chunks (2 WAVES entries) of the splits before s; word2[s]: bits 0-19 the length of split s's list, bits
+    // 20-31 the split whose PARTIAL chunk is the s-th of the partial chunks (two arrays in one)
+    unsigned *pre = dyn_lds, *word2 = dyn_lds + nsplits + 1;
+    constexpr unsigned PER = 2 * WAVES;
+    static_assert(kCullMaxSplits <= 4096 && (PER & (PER - 1)) == 0, "12 bits of split, chunks of a power of two");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int done = st ? st->done : 0;
+    __shared__ unsigned s_full, s_total;
     if (wave == 0) {
         unsigned run = 0, listed = 0;
         for (int s0 = 0; s0 < nsplits; s0 += 64) {
             const int s = s0 + lane;
             const unsigned c = s < nsplits ? cnt[s] : 0u;
-            const unsigned ch = (c + 2 * WAVES - 1) / (2 * WAVES);
+            const unsigned ch = c / PER;
             const unsigned inc = wave_scan_incl(ch);
             const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)wave_scan_incl(c), 63);
             if (s < nsplits) {
                 pre[s] = run + inc - ch;
-                lcnt[s] = c;
+                word2[s] = c; // (< 2^20: at most n / 32 entries, n < 2^25 -- engine_for)
             }
             run += (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
             listed += tot;
         }
+        // the partial chunks (the last, short chunk of a list) behind all the full ones, the longer ones first: the chunks
+        // are handed out in index order, so the kernel's tail -- the last chunks, each alone on its CU -- is made of
+        // the cheapest ones (a chunk of two tiles keeps one wave busy, a full one eight)
+        unsigned parts = 0;
+#pragma unroll 1
+        for (int cls = 3; cls >= 0; --cls) {
+            for (int s0 = 0; s0 < nsplits; s0 += 64) {
+                const int s = s0 + lane;
+                const unsigned rem = s < nsplits ? (word2[s] & 0xFFFFFu) % PER : 0u;
+                const bool in = rem != 0u && (int)(rem * 4u / PER) == cls;
+                const unsigned long long mask = __ballot(in);
+                if (in) atomicOr(&word2[parts + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))], (unsigned)s << 20);
+                parts += (unsigned)__popcll(mask);
+            }
+        }
         if (lane == 0) {
             pre[nsplits] = run;
+            s_full = run;
+            s_total = run + parts;
             if (blockIdx.x == 0 && stats && !done) {
                 atomicAdd(stats, (unsigned long long)listed);
                 atomicAdd(stats + 1, pairs_total);
@@ -514,19 +537,27 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
 #ifdef ICPMI_GROUPS_CLOCKS
     stamp[1] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const unsigned total = pre[nsplits];
+    const unsigned nfull = s_full, total = s_total;
     // chunk c -> its split, and this wave's two list entries (requested, not waited for)
     auto lookup = [&](const unsigned c, int &s, bool &active, bool &active_b, uint2 &gv) {
-        int slo = 0, shi = nsplits; // pre[slo] <= c < pre[shi]
-        while (shi - slo > 1) {
-            const int mid = (slo + shi) >> 1;
-            if (pre[mid] <= c) slo = mid;
-            else shi = mid;
+        unsigned item, len;
+        if (c < nfull) { // (workgroup-uniform)
+            int slo = 0, shi = nsplits; // pre[slo] <= c < pre[shi]
+            while (shi - slo > 1) {
+                const int mid = (slo + shi) >> 1;
+                if (pre[mid] <= c) slo = mid;
+                else shi = mid;
+            }
+            s = __builtin_amdgcn_readfirstlane(slo);
+            len = word2[s] & 0xFFFFFu;
+            item = (c - pre[s]) * PER + 2u * (unsigned)wave; // (even: cap is even, the pair is 8-byte aligned)
+        } else {
+            s = __builtin_amdgcn_readfirstlane((int)(word2[c - nfull] >> 20));
+            len = word2[s] & 0xFFFFFu;
+            item = (len & ~(PER - 1u)) + 2u * (unsigned)wave;
         }
-        s = __builtin_amdgcn_readfirstlane(slo);
-        const unsigned item = (c - pre[s]) * (2 * WAVES) + 2u * (unsigned)wave; // (even: cap is even, the pair is 8-byte aligned)
-        active = item < lcnt[s];
-        active_b = item + 1u < lcnt[s];
+        active = item < len;
+        active_b = item + 1u < len;
         gv = active ? *reinterpret_cast<const uint2 *>(items + (size_t)s * cap + item) : make_uint2(0u, 0u);
     };
     unsigned c = blockIdx.x;

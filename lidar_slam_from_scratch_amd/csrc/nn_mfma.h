@@ -1107,7 +1107,7 @@ constexpr int kResolveWW = ICPMI_RESOLVE_WW;
 // fused residual + normal-equation terms.  (jspec, q*, n*): the matched target and normal gathered ahead for target
 // `jspec` (< 0: nothing was gathered).
 template <int Q>
-__device__ __forceinline__ void resolve_finish(const int lane, const int wave, const int ql, const int sub, const int i,
+__device__ __forceinline__ void resolve_finish(const int lane, const int wave, const int ql, const bool owner /* ONE lane of each query */, const int i,
                                                const bool valid, const double bd, const int bj, const double px,
                                                const double py, const double pz, const int m, int *__restrict__ idx,
                                                double *__restrict__ d2out, unsigned long long *__restrict__ counters,
@@ -1116,7 +1116,7 @@ __device__ __forceinline__ void resolve_finish(const int lane, const int wave, c
                                                double *__restrict__ partials, const int jspec, double q0, double q1,
                                                double q2, double n0, double n1, double n2)
 {
-    if (valid && sub == 0) {
+    if (valid && owner) {
         idx[i] = bj == 0x7fffffff ? -1 : bj; // NaN/Inf query: nothing compares less (kdtree.hpp:53)
         if (d2out) d2out[i] = bd;
     }
@@ -1147,7 +1147,7 @@ __device__ __forceinline__ void resolve_finish(const int lane, const int wave, c
         // column l & 31 over the Q / 2 rows of half l >> 5 and the halves meet with one exchange
         __shared__ double jrow[kResolveWW][Q][29];
         __shared__ double red[kResolveWW][28];
-        if (sub == 0) { // each term goes to LDS as it is formed (28 live doubles would cost 2 waves per SIMD)
+        if (owner) { // each term goes to LDS as it is formed (28 live doubles would cost 2 waves per SIMD)
             double J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, b = 0.0;
             if (valid) {
                 const int j = (unsigned)bj < (unsigned)m ? bj : 0;
@@ -1182,7 +1182,7 @@ __device__ __forceinline__ void resolve_finish(const int lane, const int wave, c
 #pragma unroll
                 for (int r = 0; r < Q / 2; ++r) v += jrow[wave][h * (Q / 2) + r][c];
             }
-            v += __shfl_xor(v, 32, 64);
+            v += lane_xor<32>(v);
             if (lane < 28) red[wave][lane] = v;
         }
         __syncthreads();
@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     unsigned extra_slots = 0, extra_splits = 0;
     resolve_certify<SUBS, Q, KEEP, ICPMI_RESOLVE_SCANBATCH>(pv, lane, sub, valid, ic, n, px, py, pz, coarse, splits, slist, nact, frames, gframe, bs, sorted, perm, m, ms,
                              bd, bj, extra_slots, extra_splits);
-    resolve_finish<Q>(lane, wave, ql, sub, i, valid, bd, bj, px, py, pz, m, idx, d2out, counters, extra_slots, extra_splits,
+    resolve_finish<Q>(lane, wave, ql, sub == 0, i, valid, bd, bj, px, py, pz, m, idx, d2out, counters, extra_slots, extra_splits,
                       tgt_orig, nrm, partials, jspec, q0, q1, q2, n0, n1, n2);
 }
 
@@ -1615,7 +1615,7 @@ __device__ __forceinline__ T wave_sort_asc(T v, int lane)
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const T o = __shfl_xor(v, j, 64);
+            const T o = lane_xor_n(v, j);
             const bool up = (lane & k) == 0, lower = (lane & j) == 0;
             const T mn = o < v ? o : v, mx = o < v ? v : o;
             v = (lower == up) ? mn : mx;
