@@ -57,7 +57,9 @@ extern "C" {
                                         boxes are farther apart than the tile's known neighbour distance -- the
                                         rule of kdtree.hpp:139,177 applied to groups; same exact result, not an
                                         all-pairs pass (registrations and normal estimation).  AUTO takes it for
-                                        targets of more than 12 splits (24,576 points), engine 2 below that */
+                                        targets of more than 12 splits (24,576 points), engine 2 below that; targets
+                                        of more than 3,072 splits (6.29M points) or sources of 2^25 rows and more
+                                        run on engine 2 whichever of the two was asked for */
 
 typedef struct icpmi_ctx icpmi_ctx;
 
