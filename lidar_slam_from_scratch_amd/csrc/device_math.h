@@ -51,12 +51,37 @@ template <int S> __device__ __forceinline__ int row16_partner(int v)
 {
     static_assert(S >= 0 && S < 4, "four steps");
     constexpr int ctrl = S == 0 ? 0xB1 : S == 1 ? 0x4E : S == 2 ? 0x141 : 0x140;
-    return __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);
+    return __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true); // (every lane has a source: nothing is left undefined)
 }
 template <int S> __device__ __forceinline__ float row16_partner(float v) { return __int_as_float(row16_partner<S>(__float_as_int(v))); }
 template <int S> __device__ __forceinline__ double row16_partner(double v)
 {
     return __hiloint2double(row16_partner<S>(__double2hiint(v)), row16_partner<S>(__double2loint(v)));
+}
+
+// (d, j) <- the smallest (distance, index) pair among the 16 lanes of a row, in every lane of it: the minimum of d first
+// (v_min_f64 on the DPP partners; d is never a NaN here), then the smallest index among the lanes that hold it -- 22
+// vector instructions where the pairwise form (three compares and three selects per step) takes 36.
+__device__ __forceinline__ double vmin_f64(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); // (no canonicalisation around it: operands are numbers)
+    return r;
+}
+__device__ __forceinline__ void row16_argmin(double &d, int &j)
+{
+    double m = d;
+    m = vmin_f64(m, row16_partner<0>(m));
+    m = vmin_f64(m, row16_partner<1>(m));
+    m = vmin_f64(m, row16_partner<2>(m));
+    m = vmin_f64(m, row16_partner<3>(m));
+    int jj = d == m ? j : 0x7fffffff;
+    jj = min(jj, row16_partner<0>(jj));
+    jj = min(jj, row16_partner<1>(jj));
+    jj = min(jj, row16_partner<2>(jj));
+    jj = min(jj, row16_partner<3>(jj));
+    d = m;
+    j = jj;
 }
 
 // __shfl_xor(v, X, 64) without the LDS crossbar: the value of lane ^ X by vector-ALU moves.  X = 1, 2: quad permutations;
@@ -67,12 +92,12 @@ template <int S> __device__ __forceinline__ double row16_partner(double v)
 template <int X> __device__ __forceinline__ int lane_xor(int v)
 {
     static_assert(X == 1 || X == 2 || X == 4 || X == 8 || X == 16 || X == 32, "one bit");
-    if constexpr (X == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
-    else if constexpr (X == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
-    else if constexpr (X == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);
+    if constexpr (X == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true); // (every lane has a source lane)
+    else if constexpr (X == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);
+    else if constexpr (X == 8) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);
     else if constexpr (X == 4) {
-        const int below = __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false); // lane - 4 (mod 16)
-        const int above = __builtin_amdgcn_update_dpp(v, v, 0x12C, 0xf, 0xf, false); // lane + 4 (mod 16)
+        const int below = __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, true); // lane - 4 (mod 16)
+        const int above = __builtin_amdgcn_mov_dpp(v, 0x12C, 0xf, 0xf, true); // lane + 4 (mod 16)
         return (__lane_id() & 4) ? below : above;
     } else if constexpr (X == 16) {
         const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);

@@ -277,16 +277,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_icp_small(
     }
     double bd = ld;
     int bj = lj;
-#define ICPMI_STEP(S)                                                                 \
-    {                                                                                 \
-        const double od = row16_partner<S>(bd);                                       \
-        const int oj = row16_partner<S>(bj);                                          \
-        const bool take = (od < bd) | ((od == bd) & (oj < bj));                       \
-        bd = take ? od : bd;                                                          \
-        bj = take ? oj : bj;                                                          \
-    }
-    ICPMI_STEP(0) ICPMI_STEP(1) ICPMI_STEP(2) ICPMI_STEP(3)
-#undef ICPMI_STEP
+    row16_argmin(bd, bj);
     ICPMI_SMALL_STAMP(4); // slots scanned
 
     // certificate: every split's record against its bound (resolve_certify without the first filter:

@@ -32,8 +32,49 @@ namespace icpmi {
 constexpr int kNnSlotCap = 16; // listed slots scanned per row
 
 // Q = 16 queries per wave, the lane layout, workgroup shape and sums of k_nn_resolve<16>.
+// One lane's share of a slot -- sorted positions j0 + 16 o, o < kSlotTargets / 16 -- requested in ONE batch: the loads of
+// all of them are issued before the first is waited for.  (Written as load-then-use per candidate, the compiler kept each
+// candidate's four loads next to their use -- fewer live registers -- and a slot became kSlotTargets / 16 dependent memory
+// round trips, a wave's four rounds sixteen: with every wave of a C3 pass resident at once the kernel's time IS one wave's
+// chain of trips.)  Addresses are a scalar base + a 32-bit byte offset per candidate (positions < 2^28).
+struct SlotBatch {
+    static constexpr int N = kSlotTargets / 16;
+    double x[N], y[N], z[N];
+    int oj[N];
+    __device__ __forceinline__ void load(const double *__restrict__ sorted, const unsigned *__restrict__ perm, const int m, const int ms,
+                                         const int j0)
+    {
+        const char *bx = reinterpret_cast<const char *>(sorted), *by = reinterpret_cast<const char *>(sorted + (size_t)ms),
+                   *bz = reinterpret_cast<const char *>(sorted + 2 * (size_t)ms), *bp = reinterpret_cast<const char *>(perm);
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+            // (clamped: with a bound beyond the padding's stand-in distance a row lists padding slots too, whose positions
+            // lie outside the sorted copy; dropped by j < m in the evaluation)
+            const unsigned jj = (unsigned)(j0 + 16 * o), jc = jj < (unsigned)m ? jj : (unsigned)(m - 1);
+            x[o] = *reinterpret_cast<const double *>(bx + (jc << 3));
+            y[o] = *reinterpret_cast<const double *>(by + (jc << 3));
+            z[o] = *reinterpret_cast<const double *>(bz + (jc << 3));
+            oj[o] = *reinterpret_cast<const int *>(bp + (jc << 2));
+        }
+        __builtin_amdgcn_sched_barrier(0); // (the scheduler moves nothing across: all requested before any is used; the waits stay progressive)
+    }
+    // (distance, original index) minimum with the candidates of this batch; selects, not branches: written with `if` and
+    // short-circuit operators every update of a lane became an exec-mask save, a branch and a restore
+    __device__ __forceinline__ void eval(const int m, const int j0, const bool act, const double qx, const double qy, const double qz,
+                                         double &d, int &jo) const
+    {
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+            const double dd = sqdist(x[o], y[o], z[o], qx, qy, qz);
+            const bool take = act & (j0 + 16 * o < m) & ((dd < d) | ((dd == d) & (oj[o] < jo)));
+            d = take ? dd : d;
+            jo = take ? oj[o] : jo;
+        }
+    }
+};
+
 #ifndef ICPMI_BOUNDED_OCC
-#define ICPMI_BOUNDED_OCC 7 /* waves per SIMD the register allocation must allow: at 7 (72 VGPRs, 3 dwords spilled) all 6,252 waves of a C3 pass are resident at once -- 5 / 6 / 7 / 8: 28.4 / 28.5 / 25.6 / 28.8 us (scripts/sweep_bounded_occ.sh) */
+#define ICPMI_BOUNDED_OCC 5 /* waves per SIMD the register allocation must allow.  With a slot's loads requested as a batch (SlotBatch: 28 registers in flight) the kernel wants ~107 registers: at 5 (96, nothing spilled) 19.8 us per C3 pass, at 6 (40 dwords spilled) 24.2, at 7 (72 registers, more spilled) 30.4, at 4 or 3 with two or four rounds' loads in flight 20.0-20.2 (scripts/ab_kernels.sh, same box).  Before the batch -- every candidate's loads next to their use, sixteen dependent trips per wave -- 7 was the best (22.1; 5 / 6 / 7 / 8: 28.4 / 28.5 / 25.6 / 28.8 in round 3's form) */
 #endif
 __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu(ICPMI_BOUNDED_OCC, 8))) void k_nn_resolve_bounded(
     const double *__restrict__ qry, int n, const double *__restrict__ sorted, const unsigned *__restrict__ perm, int m, int ms,
@@ -96,19 +137,9 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     double qx[ROUNDS], qy[ROUNDS], qz[ROUNDS];
     auto scan_slot = [&](const int r, const int slot, const bool act) {
         const int j0 = (slot / kCols) * kSplitTargets + (slot % kCols) * kSlotTargets + l16;
-#pragma unroll
-        for (int o = 0; o < kSlotTargets / 16; ++o) {
-            // (clamped: with a bound beyond the padding's stand-in distance a row lists padding slots too, whose positions
-            // lie outside the sorted copy; dropped by jj < m)
-            const int jj = j0 + 16 * o, jc = jj < m ? jj : m - 1;
-            const int oj = (int)perm[jc];
-            const double dd = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), qx[r], qy[r], qz[r]);
-            // (selects, not branches: written with `if` and short-circuit operators every one of the sixteen updates of a
-            // lane became an exec-mask save, a branch and a restore -- 178 s_and_saveexec / 165 s_cbranch in the kernel)
-            const bool take = act & (jj < m) & ((dd < d[r]) | ((dd == d[r]) & (oj < jo[r])));
-            d[r] = take ? dd : d[r];
-            jo[r] = take ? oj : jo[r];
-        }
+        SlotBatch b;
+        b.load(sorted, perm, m, ms, j0);
+        b.eval(m, j0, act, qx[r], qy[r], qz[r], d[r], jo[r]);
     };
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -120,8 +151,26 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
         d[r] = kMax;
         jo[r] = 0x7fffffff;
     }
+    {   // the first listed slot of the quarter's four queries, ICPMI_BOUNDED_BATCH rounds' loads in flight together
+#ifndef ICPMI_BOUNDED_BATCH
+#define ICPMI_BOUNDED_BATCH 1
+#endif
+        constexpr int RB = ICPMI_BOUNDED_BATCH;
+        static_assert(ROUNDS % RB == 0, "whole batches");
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) scan_slot(r, __shfl(first_slot, quarter * ROUNDS + r, 64), ns[r] > 0);
+        for (int r0 = 0; r0 < ROUNDS; r0 += RB) {
+            SlotBatch b[RB];
+            int j0[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int slot = __shfl(first_slot, quarter * ROUNDS + r0 + u, 64);
+                j0[u] = (slot / kCols) * kSplitTargets + (slot % kCols) * kSlotTargets + l16;
+                b[u].load(sorted, perm, m, ms, j0[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) b[u].eval(m, j0[u], ns[r0 + u] > 0, qx[r0 + u], qy[r0 + u], qz[r0 + u], d[r0 + u], jo[r0 + u]);
+        }
+    }
 #if defined(ICPMI_NNB_STOP) && ICPMI_NNB_STOP == 2
     if (nsl_eff >= 0) { if (valid && sub == 0) idx[i] = jo[0] + jo[1] + jo[2] + jo[3] + (int)(d[0] + d[1] + d[2] + d[3]); return; }
 #endif
@@ -146,16 +195,7 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-#define ICPMI_STEP(S)                                                                     \
-        {                                                                                 \
-            const double od = row16_partner<S>(d[r]);                                     \
-            const int oj = row16_partner<S>(jo[r]);                                       \
-            const bool take = (od < d[r]) | ((od == d[r]) & (oj < jo[r]));                \
-            d[r] = take ? od : d[r];                                                      \
-            jo[r] = take ? oj : jo[r];                                                    \
-        }
-        ICPMI_STEP(0) ICPMI_STEP(1) ICPMI_STEP(2) ICPMI_STEP(3)
-#undef ICPMI_STEP
+        row16_argmin(d[r], jo[r]);
     }
     // Query ql was scanned by quarter ql / ROUNDS in round ql % ROUNDS, and every lane of that quarter holds the result: the
     // query's sub-lane IN that quarter is its OWNER from here on (incumbent, exhaustive search, terms) -- no exchange
@@ -271,12 +311,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4_bounded(
     int jo = 0x7fffffff;
     auto scan_slot = [&](const int slot, const bool act) {
         const int j0 = (slot / kCols) * kSplitTargets + (slot % kCols) * kSlotTargets + ql;
+        // (load-then-use per candidate, not SlotBatch: one slot per quarter here, and the compiler's own order -- which
+        // keeps the four candidates' loads in flight in this kernel -- measured 4 % faster than the forced batch)
 #pragma unroll
         for (int o = 0; o < kSlotTargets / 16; ++o) {
-            const int jj = j0 + 16 * o, jc = jj < m ? jj : m - 1; // (clamped: see k_nn_resolve_bounded)
+            const int jj = j0 + 16 * o, jc = jj < m ? jj : m - 1; // (clamped: see SlotBatch)
             const int oj = (int)perm[jc];
             const double dd = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), px, py, pz);
-            const bool take = act & (jj < m) & ((dd < d) | ((dd == d) & (oj < jo))); // (selects, not branches: k_nn_resolve_bounded)
+            const bool take = act & (jj < m) & ((dd < d) | ((dd == d) & (oj < jo))); // (selects, not branches: SlotBatch)
             d = take ? dd : d;
             jo = take ? oj : jo;
         }
@@ -294,16 +336,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4_bounded(
         __builtin_amdgcn_wave_barrier();
         for (int t = 1; __ballot(t < ns) != 0ull; ++t) scan_slot(t < ns ? flist[wave][quarter][t] : 0, t < ns);
     }
-#define ICPMI_STEP(S)                                                                 \
-    {                                                                                 \
-        const double od = row16_partner<S>(d);                                        \
-        const int oj = row16_partner<S>(jo);                                          \
-        const bool take = (od < d) | ((od == d) & (oj < jo));                         \
-        d = take ? od : d;                                                            \
-        jo = take ? oj : jo;                                                          \
-    }
-    ICPMI_STEP(0) ICPMI_STEP(1) ICPMI_STEP(2) ICPMI_STEP(3)
-#undef ICPMI_STEP
+    row16_argmin(d, jo);
     {
         const bool take = look & ((d < bd) | ((d == bd) & (jo < bj)));
         bd = take ? d : bd;
