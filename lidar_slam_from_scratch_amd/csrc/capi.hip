@@ -528,6 +528,7 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     if (ctx->nn_pruned) engine = ICPMI_SEARCH_MFMA_BF16;
     ctx->nn_engine = engine;
     if (engine != ICPMI_SEARCH_MFMA_BF16) return ICPMI_OK;
+    if (m >= (1 << 27)) return fail(ctx, ICPMI_ERR_ARG, "the MFMA engines take targets of fewer than 2^27 points (32-bit byte offsets into the sorted records)");
     const int splits = (m + kSplitTargets - 1) / kSplitTargets;
     ctx->nn_splits = splits;
     int rc;
@@ -541,7 +542,7 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     if ((rc = reserve(ctx, ctx->sort_tmp, sort_bytes))) return rc;
     const int ms = (m + 63) / 64 * 64; // component stride of the SoA sorted copy
     ctx->nn_ms = ms;
-    if ((rc = reserve(ctx, ctx->tgt_sorted, sizeof(double) * 3 * (size_t)ms))) return rc;
+    if ((rc = reserve(ctx, ctx->tgt_sorted, sizeof(double) * sorted_doubles(ms)))) return rc; // three planes + the records (nn_mfma.h)
     if ((rc = reserve(ctx, ctx->frames, frames_bytes(splits)))) return rc; // split frames, then the slots' boxes
     NnFrame *frame = (NnFrame *)ctx->nn_misc.p;
     unsigned *keys_in = (unsigned *)ctx->sort_keys.p, *keys_out = keys_in + m, *vals_in = keys_in + 2 * (size_t)m,
@@ -560,7 +561,7 @@ int prepare_nn(icpmi_ctx *ctx, const double *d_tgt, int m, int n_hint)
     hipLaunchKernelGGL(k_morton_keys, dim3((m + 255) / 256), dim3(256), 0, s, d_tgt, m, (const NnFrame *)frame,
                        keys_in, vals_in);
     HIP_TRY(ctx, sort_pairs_u32(ctx->sort_tmp.p, &sort_bytes, keys_in, keys_out, vals_in, perm, (unsigned)m, s));
-    hipLaunchKernelGGL(k_gather_points, dim3((m + 255) / 256), dim3(256), 0, s, d_tgt, (const unsigned *)perm, m, ms,
+    hipLaunchKernelGGL(k_gather_points_rec, dim3((m + 255) / 256), dim3(256), 0, s, d_tgt, (const unsigned *)perm, m, ms,
                        (double *)ctx->tgt_sorted.p);
     hipLaunchKernelGGL(k_split_frames, dim3(splits), dim3(256), 0, s, (const double *)ctx->tgt_sorted.p, m, ms,
                        (SplitFrame *)ctx->frames.p);

@@ -36,7 +36,7 @@ constexpr int kNnSlotCap = 16; // listed slots scanned per row
 // all of them are issued before the first is waited for.  (Written as load-then-use per candidate, the compiler kept each
 // candidate's four loads next to their use -- fewer live registers -- and a slot became kSlotTargets / 16 dependent memory
 // round trips, a wave's four rounds sixteen: with every wave of a C3 pass resident at once the kernel's time IS one wave's
-// chain of trips.)  Addresses are a scalar base + a 32-bit byte offset per candidate (positions < 2^28).
+// chain of trips.)  Addresses are a scalar base + a 32-bit byte offset per candidate (positions < 2^27).
 struct SlotBatch {
     static constexpr int N = kSlotTargets / 16;
     double x[N], y[N], z[N];
@@ -44,17 +44,20 @@ struct SlotBatch {
     __device__ __forceinline__ void load(const double *__restrict__ sorted, const unsigned *__restrict__ perm, const int m, const int ms,
                                          const int j0)
     {
-        const char *bx = reinterpret_cast<const char *>(sorted), *by = reinterpret_cast<const char *>(sorted + (size_t)ms),
-                   *bz = reinterpret_cast<const char *>(sorted + 2 * (size_t)ms), *bp = reinterpret_cast<const char *>(perm);
+        // the candidates' RECORDS (nn_mfma.h: x, y, z, original index in 32 bytes): two 16-byte loads each, where the
+        // three planes and the permutation are four
+        const char *rec = reinterpret_cast<const char *>(sorted_records(sorted, ms));
+        (void)perm;
 #pragma unroll
         for (int o = 0; o < N; ++o) {
             // (clamped: with a bound beyond the padding's stand-in distance a row lists padding slots too, whose positions
             // lie outside the sorted copy; dropped by j < m in the evaluation)
             const unsigned jj = (unsigned)(j0 + 16 * o), jc = jj < (unsigned)m ? jj : (unsigned)(m - 1);
-            x[o] = *reinterpret_cast<const double *>(bx + (jc << 3));
-            y[o] = *reinterpret_cast<const double *>(by + (jc << 3));
-            z[o] = *reinterpret_cast<const double *>(bz + (jc << 3));
-            oj[o] = *reinterpret_cast<const int *>(bp + (jc << 2));
+            const uint4 a = *reinterpret_cast<const uint4 *>(rec + (jc << 5)), b = *reinterpret_cast<const uint4 *>(rec + (jc << 5) + 16);
+            x[o] = __hiloint2double((int)a.y, (int)a.x);
+            y[o] = __hiloint2double((int)a.w, (int)a.z);
+            z[o] = __hiloint2double((int)b.y, (int)b.x);
+            oj[o] = (int)b.z;
         }
         __builtin_amdgcn_sched_barrier(0); // (the scheduler moves nothing across: all requested before any is used; the waits stay progressive)
     }
@@ -128,53 +131,15 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     if (nsl_eff >= 0) { if (valid && sub == 0) idx[i] = first_slot + (int)bd; return; }
 #endif
 
-    // exact evaluation of the listed slots, one query per quarter-wave and round (lane takes l16, l16+16, ...: coalesced).
-    // The first slot of the quarter's four queries is scanned with the loads of all four rounds in flight together, the
-    // original indices beside the coordinates (as a chain of dependent trips this kernel was twice as long as the one
-    // it replaces: it waits on memory, not on instructions).
-    double d[ROUNDS];
-    int jo[ROUNDS], ns[ROUNDS];
-    double qx[ROUNDS], qy[ROUNDS], qz[ROUNDS];
-    auto scan_slot = [&](const int r, const int slot, const bool act) {
-        const int j0 = (slot / kCols) * kSplitTargets + (slot % kCols) * kSlotTargets + l16;
-        SlotBatch b;
-        b.load(sorted, perm, m, ms, j0);
-        b.eval(m, j0, act, qx[r], qy[r], qz[r], d[r], jo[r]);
-    };
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int src = quarter * ROUNDS + r; // the query this quarter scans in round r (a lane with sub == 0)
-        // (measured and dropped: the coordinates by a load of their own instead of six LDS crossbar trips -- twelve more
-        // vector-memory instructions per lane in a kernel that waits on memory: 22.6 -> 23.8 us at C3, same box)
-        qx[r] = __shfl(px, src, 64), qy[r] = __shfl(py, src, 64), qz[r] = __shfl(pz, src, 64);
-        ns[r] = __shfl(nsl_eff, src, 64);
-        d[r] = kMax;
-        jo[r] = 0x7fffffff;
-    }
-    {   // the first listed slot of the quarter's four queries, ICPMI_BOUNDED_BATCH rounds' loads in flight together
-#ifndef ICPMI_BOUNDED_BATCH
-#define ICPMI_BOUNDED_BATCH 1
-#endif
-        constexpr int RB = ICPMI_BOUNDED_BATCH;
-        static_assert(ROUNDS % RB == 0, "whole batches");
-#pragma unroll
-        for (int r0 = 0; r0 < ROUNDS; r0 += RB) {
-            SlotBatch b[RB];
-            int j0[RB];
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                const int slot = __shfl(first_slot, quarter * ROUNDS + r0 + u, 64);
-                j0[u] = (slot / kCols) * kSplitTargets + (slot % kCols) * kSlotTargets + l16;
-                b[u].load(sorted, perm, m, ms, j0[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < RB; ++u) b[u].eval(m, j0[u], ns[r0 + u] > 0, qx[r0 + u], qy[r0 + u], qz[r0 + u], d[r0 + u], jo[r0 + u]);
-        }
-    }
-#if defined(ICPMI_NNB_STOP) && ICPMI_NNB_STOP == 2
-    if (nsl_eff >= 0) { if (valid && sub == 0) idx[i] = jo[0] + jo[1] + jo[2] + jo[3] + (int)(d[0] + d[1] + d[2] + d[3]); return; }
-#endif
-    if (__ballot(nsl_eff > 1) != 0ull) { // further slots: through LDS, sub-lane `sub` expands its two words
+    // exact evaluation of the listed slots, one query per quarter-wave and round (lane takes l16, l16+16, ...: coalesced),
+    // the original indices beside the coordinates.  Round by round -- query, first slot, further slots, the quarter's
+    // minimum, the owner's update -- so that only one round's distances, indices and query are live at a time.
+    // Query ql is scanned by quarter ql / ROUNDS in round ql % ROUNDS, and every lane of that quarter ends up with the
+    // result: the query's sub-lane IN that quarter is its OWNER from here on (incumbent, exhaustive search, terms) -- no
+    // exchange between the rows of 16 lanes (as a gather from the scanning quarter this was twelve LDS crossbar trips).
+    const bool own = sub == ql / ROUNDS;
+    const bool more = __ballot(nsl_eff > 1) != 0ull; // further slots: through LDS, sub-lane `sub` expands its two words
+    if (more) {
         int pos = incl - mine;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -188,31 +153,29 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
             }
         }
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r)
-            for (int t = 1; __ballot(t < ns[r]) != 0ull; ++t)
-                scan_slot(r, t < ns[r] ? flist[wave][quarter * ROUNDS + r][t] : 0, t < ns[r]);
     }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        row16_argmin(d[r], jo[r]);
-    }
-    // Query ql was scanned by quarter ql / ROUNDS in round ql % ROUNDS, and every lane of that quarter holds the result: the
-    // query's sub-lane IN that quarter is its OWNER from here on (incumbent, exhaustive search, terms) -- no exchange
-    // between the rows of 16 lanes (as a gather from the scanning quarter this was twelve LDS crossbar trips per wave)
-    const bool own = sub == ql / ROUNDS;
-    {
-        double rd = d[0];
-        int rj = jo[0];
-#pragma unroll
-        for (int r = 1; r < ROUNDS; ++r) {
-            const bool sel = (ql % ROUNDS) == r;
-            rd = sel ? d[r] : rd;
-            rj = sel ? jo[r] : rj;
-        }
-        const bool take = own & look & ((rd < bd) | ((rd == bd) & (rj < bj)));
-        bd = take ? rd : bd;
-        bj = take ? rj : bj;
+        const int src = quarter * ROUNDS + r; // the query this quarter scans in round r (a lane with sub == 0)
+        // (measured and dropped: the coordinates by a load of their own instead of six LDS crossbar trips -- twelve more
+        // vector-memory instructions per lane in a kernel that waits on memory: 22.6 -> 23.8 us at C3, same box)
+        const double qx = __shfl(px, src, 64), qy = __shfl(py, src, 64), qz = __shfl(pz, src, 64);
+        const int nsr = __shfl(nsl_eff, src, 64);
+        double d = kMax;
+        int jo = 0x7fffffff;
+        auto scan_slot = [&](const int slot, const bool act) {
+            const int j0 = (slot / kCols) * kSplitTargets + (slot % kCols) * kSlotTargets + l16;
+            SlotBatch b;
+            b.load(sorted, perm, m, ms, j0);
+            b.eval(m, j0, act, qx, qy, qz, d, jo);
+        };
+        scan_slot(__shfl(first_slot, src, 64), nsr > 0);
+        if (more)
+            for (int t = 1; __ballot(t < nsr) != 0ull; ++t) scan_slot(t < nsr ? flist[wave][src][t] : 0, t < nsr);
+        row16_argmin(d, jo);
+        const bool take = own & ((ql % ROUNDS) == r) & look & ((d < bd) | ((d == bd) & (jo < bj)));
+        bd = take ? d : bd;
+        bj = take ? jo : bj;
     }
 
 #if defined(ICPMI_NNB_STOP) && ICPMI_NNB_STOP == 3
@@ -313,11 +276,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4_bounded(
         const int j0 = (slot / kCols) * kSplitTargets + (slot % kCols) * kSlotTargets + ql;
         // (load-then-use per candidate, not SlotBatch: one slot per quarter here, and the compiler's own order -- which
         // keeps the four candidates' loads in flight in this kernel -- measured 4 % faster than the forced batch)
+        const uint4 *rec = sorted_records(sorted, ms);
 #pragma unroll
         for (int o = 0; o < kSlotTargets / 16; ++o) {
             const int jj = j0 + 16 * o, jc = jj < m ? jj : m - 1; // (clamped: see SlotBatch)
-            const int oj = (int)perm[jc];
-            const double dd = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), px, py, pz);
+            const uint4 a = rec[2 * (size_t)jc], b = rec[2 * (size_t)jc + 1]; // (the record: two loads, not four)
+            const int oj = (int)b.z;
+            const double dd = sqdist(__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)a.w, (int)a.z), __hiloint2double((int)b.y, (int)b.x), px, py, pz);
             const bool take = act & (jj < m) & ((dd < d) | ((dd == d) & (oj < jo))); // (selects, not branches: SlotBatch)
             d = take ? dd : d;
             jo = take ? oj : jo;

@@ -284,6 +284,28 @@ __global__ __launch_bounds__(256) void k_gather_points(const double *__restrict_
     ICPMI_SZ(out, ms, i) = pts[3 * j + 2];
 }
 
+// The sorted copy a second time as RECORDS behind the three planes (round 4): 32 bytes per target -- x, y, z, original
+// index, pad -- so that an exact scan fetches a candidate with two 16-byte loads instead of four (three planes + the
+// permutation).  The texture-address unit takes 16 cycles for a wave's load instruction whatever its width
+// (TA_TA_BUSY / TA_FLAT_READ_WAVEFRONTS = 15.2 on the bounded resolve), and that unit was the resolve's bound: busy 75 % of
+// the kernel with 81 load instructions per wave, 64 of them the scan's.
+__host__ __device__ inline size_t sorted_doubles(int ms) { return 7 * (size_t)ms; } // 3 planes + 4 doubles' worth of record per target
+__device__ __forceinline__ const uint4 *sorted_records(const double *sorted, int ms) { return reinterpret_cast<const uint4 *>(sorted + 3 * (size_t)ms); }
+__global__ __launch_bounds__(256) void k_gather_points_rec(const double *__restrict__ pts, const unsigned *__restrict__ perm, int m, int ms,
+                                                           double *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const unsigned j = perm[i];
+    const double x = pts[3 * j], y = pts[3 * j + 1], z = pts[3 * j + 2];
+    ICPMI_SX(out, ms, i) = x;
+    ICPMI_SY(out, ms, i) = y;
+    ICPMI_SZ(out, ms, i) = z;
+    uint4 *rec = reinterpret_cast<uint4 *>(out + 3 * (size_t)ms) + 2 * (size_t)i;
+    rec[0] = make_uint4((unsigned)__double2loint(x), (unsigned)__double2hiint(x), (unsigned)__double2loint(y), (unsigned)__double2hiint(y));
+    rec[1] = make_uint4((unsigned)__double2loint(z), (unsigned)__double2hiint(z), j, 0u);
+}
+
 // one workgroup per split: bounding box of its sorted points -> centre and radius; and, behind the
 // frames, the bounding box of each of its 32 SLOTS (64 targets contiguous in the sorted array:
 // a compact blob), six doubles per slot, which let the resolve cull a whole-split scan down to the
