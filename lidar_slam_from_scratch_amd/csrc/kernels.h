@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "device_math.h"
 
@@ -208,19 +209,29 @@ __device__ inline void finish_sums(const double *__restrict__ partials, int nblo
     double acc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) acc[u] = 0.0;
-    int b = g;
-    for (; b + (U - 1) * G < nblocks; b += U * G) {
-        double v[U];
+    // Every round's loads are UNCONDITIONAL (a clamped row, its value dropped by a select: acc + 0.0 is acc, no slot ever
+    // holds -0.0) so that they are all in flight together in the last, partial round too.  Written with a guard per load that
+    // round was a chain of dependent round trips -- and below 481 rows it is the only round: eight trips for the 250 rows
+    // of a filtered scan, four for the 98 group sums of C3.  Only as many slots as the launch's rows fill are loaded (4, 8
+    // or 16: a load instruction costs the CU's address unit 16 cycles whether its lanes' rows are clamped or not -- with
+    // all sixteen slots always loaded, C3's step kernel lost 0.5 us where the filtered scan's gained 0.5).
+    const int last = nblocks - 1;
+    auto rounds = [&](auto slots) {
+        constexpr int S = decltype(slots)::value;
+        for (int b = g; b < nblocks; b += U * G) {
+            double v[S];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = partials[(size_t)(b + u * G) * kSumsStride + e];
+            for (int u = 0; u < S; ++u) {
+                const int bb = b + u * G;
+                v[u] = partials[(size_t)(bb < nblocks ? bb : last) * kSumsStride + e];
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] += v[u];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) { // the last, partial round (guarded loads, same slots)
-        const int bb = b + u * G;
-        if (bb < nblocks) acc[u] += partials[(size_t)bb * kSumsStride + e];
-    }
+            for (int u = 0; u < S; ++u) acc[u] += (b + u * G < nblocks) ? v[u] : 0.0;
+        }
+    };
+    if (nblocks <= 4 * G) rounds(std::integral_constant<int, 4>());
+    else if (nblocks <= 8 * G) rounds(std::integral_constant<int, 8>());
+    else rounds(std::integral_constant<int, U>());
 #pragma unroll
     for (int w = U / 2; w > 0; w >>= 1) // fixed pairwise order
 #pragma unroll
