@@ -473,10 +473,11 @@ template <int B>
 struct RowBatch {
     double x[B], y[B], z[B], tx[B], ty[B], tz[B];
     bool have[B];
-    __device__ __forceinline__ void load(const double *in, const RowBounds &rb, int i0, int stride, int n,
-                                         const unsigned *__restrict__ perm = nullptr)
+    int j[B];
+    // the rows and their previous matches' indices ...
+    __device__ __forceinline__ void load_rows(const double *in, const RowBounds &rb, int i0, int stride, int n,
+                                              const unsigned *__restrict__ perm = nullptr)
     {
-        int j[B];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             const int i = i0 + b * stride;
@@ -488,12 +489,24 @@ struct RowBatch {
                 if (rb.tgt) j[b] = rb.idx[i];
             }
         }
+    }
+    // ... and the matched targets, a round trip that DEPENDS on the indices: a kernel with other loads to issue (the state,
+    // the partial rows) calls this after them -- waves issue in order, so behind this gather's wait for the indices those
+    // loads would start one round trip late
+    __device__ __forceinline__ void load_matches(const RowBounds &rb)
+    {
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             have[b] = rb.tgt && (unsigned)j[b] < (unsigned)rb.m;
             tx[b] = ty[b] = tz[b] = 0.0;
             if (have[b]) tx[b] = rb.tgt[3 * (size_t)j[b]], ty[b] = rb.tgt[3 * (size_t)j[b] + 1], tz[b] = rb.tgt[3 * (size_t)j[b] + 2];
         }
+    }
+    __device__ __forceinline__ void load(const double *in, const RowBounds &rb, int i0, int stride, int n,
+                                         const unsigned *__restrict__ perm = nullptr)
+    {
+        load_rows(in, rb, i0, stride, n, perm);
+        load_matches(rb);
     }
     __device__ __forceinline__ void finish(double *out, const RowBounds &rb, int i0, int stride, int n, const double *T) const
     {
@@ -586,10 +599,11 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform(
     // or not the loop has ended; the sums are taken over only if it has not, like k_finish_step).
     const int i0 = blockIdx.x * kFinishThreads + threadIdx.x, stride = gridDim.x * kFinishThreads;
     RowBatch<kRowBatch> rows;
-    rows.load(in, rb, i0, stride, n);
+    rows.load_rows(in, rb, i0, stride, n);
     state_copy(&ls, sin);
     finish_sums(partials, nblocks, n_local, &sums);
     __syncthreads();
+    rows.load_matches(rb); // (in flight under the step)
     if (!ls.done && threadIdx.x < kNumSums) ls.sums[threadIdx.x] = sums.sums[threadIdx.x];
     __syncthreads();
     if (threadIdx.x < 64) { // the first wave (step_update_wave)

@@ -316,21 +316,26 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform_cull(
     // that target; the partial rows (k_finish_step_transform's order of business)
     double x = 0.0, y = 0.0, z = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
     bool have = false;
-    auto load_row = [&](const int i) {
-        x = y = z = tx = ty = tz = 0.0;
-        have = false;
+    int jprev = -1;
+    auto load_row = [&](const int i) { // the row and its previous match's index ...
+        x = y = z = 0.0;
+        jprev = -1;
         if (i < n) {
             x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
-            const int j = rb.idx[i];
-            have = (unsigned)j < (unsigned)rb.m;
-            if (have) tx = rb.tgt[3 * (size_t)j], ty = rb.tgt[3 * (size_t)j + 1], tz = rb.tgt[3 * (size_t)j + 2];
+            jprev = rb.idx[i];
         }
+    };
+    auto load_match = [&]() { // ... and the matched target: a round trip that depends on the index (RowBatch::load_matches)
+        tx = ty = tz = 0.0;
+        have = (unsigned)jprev < (unsigned)rb.m;
+        if (have) tx = rb.tgt[3 * (size_t)jprev], ty = rb.tgt[3 * (size_t)jprev + 1], tz = rb.tgt[3 * (size_t)jprev + 2];
     };
     load_row(i0);
     cull_stage_boxes(cl, frames, nsplits);
     state_copy(&ls, sin);
     finish_sums(partials, nblocks, n_local, &sums);
     __syncthreads();
+    load_match(); // (in flight under the step.  The splits' boxes staged here too, instead of in front: +2 % on the kernel)
     if (!ls.done && threadIdx.x < kNumSums) ls.sums[threadIdx.x] = sums.sums[threadIdx.x];
     __syncthreads();
     if (threadIdx.x < 64) { // the first wave (step_update_wave)
@@ -347,7 +352,10 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish_step_transform_cull(
     // (workgroup-uniform trip count -- block_cull has barriers: the workgroup's first row decides; a wave past the end
     // of the rows brings an empty box)
     for (int base = i0; base - (int)threadIdx.x < n; base += stride) {
-        if (base != i0) load_row(base);
+        if (base != i0) {
+            load_row(base);
+            load_match();
+        }
         const bool valid = base < n;
         const double px = ((x * r00 + y * r01) + z * r02) + t0;
         const double py = ((x * r10 + y * r11) + z * r12) + t1;
