@@ -32,50 +32,6 @@ namespace icpmi {
 constexpr int kNnSlotCap = 16; // listed slots scanned per row
 
 // Q = 16 queries per wave, the lane layout, workgroup shape and sums of k_nn_resolve<16>.
-// One lane's share of a slot -- sorted positions j0 + 16 o, o < kSlotTargets / 16 -- requested in ONE batch: the loads of
-// all of them are issued before the first is waited for.  (Written as load-then-use per candidate, the compiler kept each
-// candidate's four loads next to their use -- fewer live registers -- and a slot became kSlotTargets / 16 dependent memory
-// round trips, a wave's four rounds sixteen: with every wave of a C3 pass resident at once the kernel's time IS one wave's
-// chain of trips.)  Addresses are a scalar base + a 32-bit byte offset per candidate (positions < 2^27).
-struct SlotBatch {
-    static constexpr int N = kSlotTargets / 16;
-    double x[N], y[N], z[N];
-    int oj[N];
-    __device__ __forceinline__ void load(const double *__restrict__ sorted, const unsigned *__restrict__ perm, const int m, const int ms,
-                                         const int j0)
-    {
-        // the candidates' RECORDS (nn_mfma.h: x, y, z, original index in 32 bytes): two 16-byte loads each, where the
-        // three planes and the permutation are four
-        const char *rec = reinterpret_cast<const char *>(sorted_records(sorted, ms));
-        (void)perm;
-#pragma unroll
-        for (int o = 0; o < N; ++o) {
-            // (clamped: with a bound beyond the padding's stand-in distance a row lists padding slots too, whose positions
-            // lie outside the sorted copy; dropped by j < m in the evaluation)
-            const unsigned jj = (unsigned)(j0 + 16 * o), jc = jj < (unsigned)m ? jj : (unsigned)(m - 1);
-            const uint4 a = *reinterpret_cast<const uint4 *>(rec + (jc << 5)), b = *reinterpret_cast<const uint4 *>(rec + (jc << 5) + 16);
-            x[o] = __hiloint2double((int)a.y, (int)a.x);
-            y[o] = __hiloint2double((int)a.w, (int)a.z);
-            z[o] = __hiloint2double((int)b.y, (int)b.x);
-            oj[o] = (int)b.z;
-        }
-        __builtin_amdgcn_sched_barrier(0); // (the scheduler moves nothing across: all requested before any is used; the waits stay progressive)
-    }
-    // (distance, original index) minimum with the candidates of this batch; selects, not branches: written with `if` and
-    // short-circuit operators every update of a lane became an exec-mask save, a branch and a restore
-    __device__ __forceinline__ void eval(const int m, const int j0, const bool act, const double qx, const double qy, const double qz,
-                                         double &d, int &jo) const
-    {
-#pragma unroll
-        for (int o = 0; o < N; ++o) {
-            const double dd = sqdist(x[o], y[o], z[o], qx, qy, qz);
-            const bool take = act & (j0 + 16 * o < m) & ((dd < d) | ((dd == d) & (oj[o] < jo)));
-            d = take ? dd : d;
-            jo = take ? oj[o] : jo;
-        }
-    }
-};
-
 #ifndef ICPMI_BOUNDED_OCC
 #define ICPMI_BOUNDED_OCC 5 /* waves per SIMD the register allocation must allow.  With a slot's loads requested as a batch (SlotBatch: 28 registers in flight) the kernel wants ~107 registers: at 5 (96, nothing spilled) 19.8 us per C3 pass, at 6 (40 dwords spilled) 24.2, at 7 (72 registers, more spilled) 30.4, at 4 or 3 with two or four rounds' loads in flight 20.0-20.2 (scripts/ab_kernels.sh, same box).  Before the batch -- every candidate's loads next to their use, sixteen dependent trips per wave -- 7 was the best (22.1; 5 / 6 / 7 / 8: 28.4 / 28.5 / 25.6 / 28.8 in round 3's form) */
 #endif

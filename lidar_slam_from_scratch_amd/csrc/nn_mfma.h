@@ -1128,6 +1128,50 @@ constexpr int kResolveWW = ICPMI_RESOLVE_WW;
 // The end of the Q-queries-per-wave resolve kernels (k_nn_resolve, k_nn_resolve_bounded): results out, counters, and the
 // fused residual + normal-equation terms.  (jspec, q*, n*): the matched target and normal gathered ahead for target
 // `jspec` (< 0: nothing was gathered).
+// One lane's share of a slot -- sorted positions j0 + 16 o, o < kSlotTargets / 16 -- requested in ONE batch: the loads of
+// all of them are issued before the first is waited for.  (Written as load-then-use per candidate, the compiler kept each
+// candidate's four loads next to their use -- fewer live registers -- and a slot became kSlotTargets / 16 dependent memory
+// round trips, a wave's four rounds sixteen: with every wave of a C3 pass resident at once the kernel's time IS one wave's
+// chain of trips.)  Addresses are a scalar base + a 32-bit byte offset per candidate (positions < 2^27).
+struct SlotBatch {
+    static constexpr int N = kSlotTargets / 16;
+    double x[N], y[N], z[N];
+    int oj[N];
+    __device__ __forceinline__ void load(const double *__restrict__ sorted, const unsigned *__restrict__ perm, const int m, const int ms,
+                                         const int j0)
+    {
+        // the candidates' RECORDS (nn_mfma.h: x, y, z, original index in 32 bytes): two 16-byte loads each, where the
+        // three planes and the permutation are four
+        const char *rec = reinterpret_cast<const char *>(sorted_records(sorted, ms));
+        (void)perm;
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+            // (clamped: with a bound beyond the padding's stand-in distance a row lists padding slots too, whose positions
+            // lie outside the sorted copy; dropped by j < m in the evaluation)
+            const unsigned jj = (unsigned)(j0 + 16 * o), jc = jj < (unsigned)m ? jj : (unsigned)(m - 1);
+            const uint4 a = *reinterpret_cast<const uint4 *>(rec + (jc << 5)), b = *reinterpret_cast<const uint4 *>(rec + (jc << 5) + 16);
+            x[o] = __hiloint2double((int)a.y, (int)a.x);
+            y[o] = __hiloint2double((int)a.w, (int)a.z);
+            z[o] = __hiloint2double((int)b.y, (int)b.x);
+            oj[o] = (int)b.z;
+        }
+        __builtin_amdgcn_sched_barrier(0); // (the scheduler moves nothing across: all requested before any is used; the waits stay progressive)
+    }
+    // (distance, original index) minimum with the candidates of this batch; selects, not branches: written with `if` and
+    // short-circuit operators every update of a lane became an exec-mask save, a branch and a restore
+    __device__ __forceinline__ void eval(const int m, const int j0, const bool act, const double qx, const double qy, const double qz,
+                                         double &d, int &jo) const
+    {
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+            const double dd = sqdist(x[o], y[o], z[o], qx, qy, qz);
+            const bool take = act & (j0 + 16 * o < m) & ((dd < d) | ((dd == d) & (oj[o] < jo)));
+            d = take ? dd : d;
+            jo = take ? oj[o] : jo;
+        }
+    }
+};
+
 template <int Q>
 __device__ __forceinline__ void resolve_finish(const int lane, const int wave, const int ql, const bool owner /* ONE lane of each query */, const int i,
                                                const bool valid, const double bd, const int bj, const double px,
@@ -1300,18 +1344,23 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
     float pv[KEEP > 0 ? KEEP : 1];
     float best = kBig;
     int bs = 0;
+    // (the loads unconditional -- a clamped split, the value dropped by a select -- so that they are all in flight together:
+    // with a guard per load the compiler makes each a load-wait-compare of its own, KEEP dependent round trips)
+    int ps[KEEP > 0 ? KEEP : 1];
 #pragma unroll
     for (int k = 0; k < KEEP; ++k) {
-        const int e = sub + SUBS * k;
-        pv[k] = kBig;
-        if (e < nact) {
-            const int s = slist ? slist[e] : e;
-            pv[k] = ICPMI_CX(coarse, n, splits, s, ic);
-            if (pv[k] < best) {
-                best = pv[k];
-                bs = s;
-            }
-        }
+        const int e = sub + SUBS * k, ec = e < nact ? e : 0;
+        ps[k] = slist ? slist[nact > 0 ? ec : 0] : ec;
+    }
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) pv[k] = ICPMI_CX(coarse, n, splits, ps[k], ic);
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const bool in = sub + SUBS * k < nact;
+        pv[k] = in ? pv[k] : kBig;
+        const bool take = in & (pv[k] < best);
+        best = take ? pv[k] : best;
+        bs = take ? ps[k] : bs;
     }
     for (int e = sub + SUBS * KEEP; e < nact; e += SUBS) {
         const int s = slist ? slist[e] : e;
@@ -1343,26 +1392,12 @@ __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu
         const int j0 = s * kSplitTargets + c * kSlotTargets + l16; // lane takes l16, l16+16, ...: coalesced
         double d = 1.7976931348623157e308;
         int j = 0x7fffffff;
-#pragma unroll ICPMI_RESOLVE_UNROLL
-        for (int o = 0; o < kSlotTargets / 16; ++o) {
-            const int jj = j0 + 16 * o;
-            const int jc = jj < m ? jj : m - 1;
-            const double dd = sqdist(ICPMI_SX(sorted, ms, jc), ICPMI_SY(sorted, ms, jc), ICPMI_SZ(sorted, ms, jc), qx, qy, qz);
-            const int oj = (int)perm[jc];
-            if (jj < m && (dd < d || (dd == d && oj < j))) {
-                d = dd;
-                j = oj;
-            }
+        {   // (the slot's candidates requested as one batch, from the 32-byte records: SlotBatch)
+            SlotBatch sb;
+            sb.load(sorted, perm, m, ms, j0);
+            sb.eval(m, j0, true, qx, qy, qz, d, j);
         }
-#pragma unroll
-        for (int x = 1; x < 16; x <<= 1) {
-            const double od = __shfl_xor(d, x, 64);
-            const int oj = __shfl_xor(j, x, 64);
-            if (od < d || (od == d && oj < j)) {
-                d = od;
-                j = oj;
-            }
-        }
+        row16_argmin(d, j);
         // query ql was scanned by quarter ql / ROUNDS in round ql % ROUNDS
         const double rd = __shfl(d, (ql / ROUNDS) * 16, 64);
         const int rj = __shfl(j, (ql / ROUNDS) * 16, 64);
@@ -1524,18 +1559,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_nn_resolve4(const double *__rest
     float pv[KEEP4 > 0 ? KEEP4 : 1];
     float best = kBig;
     int bs = 0;
+    int ps[KEEP4 > 0 ? KEEP4 : 1]; // (unconditional loads, all in flight together: see k_nn_resolve)
 #pragma unroll
     for (int k = 0; k < KEEP4; ++k) {
-        const int e = ql + 16 * k;
-        pv[k] = kBig;
-        if (e < nact) {
-            const int s = slist ? slist[e] : e;
-            pv[k] = ICPMI_CX(coarse, n, splits, s, ic);
-            if (pv[k] < best || (pv[k] == best && s < bs)) {
-                best = pv[k];
-                bs = s;
-            }
-        }
+        const int e = ql + 16 * k, ec = e < nact ? e : 0;
+        ps[k] = slist ? slist[nact > 0 ? ec : 0] : ec;
+    }
+#pragma unroll
+    for (int k = 0; k < KEEP4; ++k) pv[k] = ICPMI_CX(coarse, n, splits, ps[k], ic);
+#pragma unroll
+    for (int k = 0; k < KEEP4; ++k) {
+        const bool in = ql + 16 * k < nact;
+        pv[k] = in ? pv[k] : kBig;
+        const bool take = in & ((pv[k] < best) | ((pv[k] == best) & (ps[k] < bs)));
+        best = take ? pv[k] : best;
+        bs = take ? ps[k] : bs;
     }
     for (int e = ql + 16 * KEEP4; e < nact; e += 16) {
         const int s = slist ? slist[e] : e;
