@@ -5,6 +5,8 @@
 #                                        kernels, secondary workloads, the culled kernel's in-kernel stamps, C2 at 20k
 #        scripts/final_profile_r4.sh b   engine thresholds, offsets, frame stream, small-cloud A/B, batch
 #        scripts/final_profile_r4.sh c   the all-pairs kernel's in-kernel clock, the small-cloud regime under rocprofv3, fuzz runs
+#        scripts/final_profile_r4.sh d   bench lines, kernel stats, shard shapes, C2 / C3 timelines, stream, small-cloud A/B, fuzz, soak: the part that
+#                                        moves with every late change, once more (no counter passes)
 cd "$GRAFT_REPO_ROOT"
 O="$GRAFT_REPO_ROOT/gpurun_out/final4"
 mkdir -p "$O"
@@ -42,6 +44,27 @@ timeout -k 10 600 python scripts/run_sequence.py --data_dir /tmp/drive200 --fram
 timeout -k 10 400 python scripts/ab_small.py > "$O/ab_small.json" 2> "$O/ab_small.err" || exit 1
 timeout -k 10 300 python scripts/batch_timing.py > "$O/batch_timing.json" 2> "$O/batch_timing.err" || exit 1
 echo done b
+exit 0
+fi
+if [ "$part" = "d" ]; then # the lines that move with every late change, once more on the last code (no counter passes)
+timeout -k 10 400 python bench.py > "$O/bench.json" 2> "$O/bench.err" || exit 1
+timeout -k 10 400 python bench.py --steps 20 --warmup 5 > "$O/bench_20.json" 2> "$O/bench_20.err" || exit 1
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-traffic > "$O/stats.log" 2>&1) || exit 1
+timeout -k 10 300 python scripts/shard_overhead.py 0 > "$O/shard_overhead_default.json" 2>&1 || exit 1
+timeout -k 10 300 python scripts/shard_overhead.py 2 > "$O/shard_overhead_all_pairs.json" 2>&1 || exit 1
+bash scripts/prof_c2.sh final4/c2_20k 0 0.3 > "$O/c2_20k.log" 2>&1 || exit 1
+bash scripts/quick_prof.sh final4/c3_default 0 100000 20 3 > /dev/null 2>&1 || exit 1
+python scripts/call_timeline.py "$O/c3_default/stats" > "$O/c3_default_timeline.txt" 2>&1
+timeout -k 10 600 python scripts/bench_extra.py --c4 > "$O/bench_extra.json" 2> "$O/bench_extra.err" || exit 1
+[ -d /tmp/drive200 ] || timeout -k 10 300 python scripts/run_sequence.py --make-synthetic /tmp/drive200 --frames 0:200 > /dev/null 2>&1 || exit 1
+timeout -k 10 600 python scripts/run_sequence.py --data_dir /tmp/drive200 --frames 0:200 --oracle > "$O/sequence_200.json" 2> "$O/sequence_200.err" || exit 1
+timeout -k 10 400 python scripts/ab_small.py > "$O/ab_small.json" 2> "$O/ab_small.err" || exit 1
+timeout -k 10 300 python scripts/fuzz_stopping.py 400 52000 > "$O/fuzz_stopping.txt" 2>&1 || exit 1
+timeout -k 10 500 python scripts/fuzz_engines.py 2000 410000 > "$O/fuzz_engines.txt" 2>&1 || exit 1
+timeout -k 10 300 python scripts/fuzz_bounded.py 2500 61000 > "$O/fuzz_bounded.txt" 2>&1 || exit 1
+timeout -k 10 300 python scripts/soak_stream.py 120 > "$O/soak_stream.txt" 2>&1 || exit 1
+python scripts/prof_summary.py "$O" > "$O/summary.txt" 2>&1
+echo done d
 exit 0
 fi
 # part c
