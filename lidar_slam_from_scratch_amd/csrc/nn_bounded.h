@@ -20,8 +20,8 @@
 // applied before the search instead of after it.  A row whose list does not fit (more than kNnEntCap words or
 // kNnSlotCap slots: a pose update so large that ub spans many slots) is searched exhaustively instead, split by
 // split behind the split's bounding box and slot by slot behind the slot's (scan_split) with the incumbent's distance
-// as the radius: slower for that row (a few dozen slot scans instead of one or two), never wrong.  The first pass of a
-// call has no previous match and runs k_nn_coarse<0> + k_nn_resolve.
+// as the radius: slower for that row (a few dozen slot scans instead of one or two), never wrong.  Since round 4 the first
+// pass of a call is bounded too (k_nn_prebound1, nn_culled.h: the nearest sorted target around the row's Morton place).
 // The normal-equation terms are formed and summed exactly as in k_nn_resolve<16> (resolve_finish), so the partial rows,
 // hence history and pose, are bit-identical to the unbounded pass's.
 #pragma once
@@ -33,7 +33,7 @@ constexpr int kNnSlotCap = 16; // listed slots scanned per row
 
 // Q = 16 queries per wave, the lane layout, workgroup shape and sums of k_nn_resolve<16>.
 #ifndef ICPMI_BOUNDED_OCC
-#define ICPMI_BOUNDED_OCC 5 /* waves per SIMD the register allocation must allow.  With a slot's loads requested as a batch (SlotBatch: 28 registers in flight) the kernel wants ~107 registers: at 5 (96, nothing spilled) 19.8 us per C3 pass, at 6 (40 dwords spilled) 24.2, at 7 (72 registers, more spilled) 30.4, at 4 or 3 with two or four rounds' loads in flight 20.0-20.2 (scripts/ab_kernels.sh, same box).  Before the batch -- every candidate's loads next to their use, sixteen dependent trips per wave -- 7 was the best (22.1; 5 / 6 / 7 / 8: 28.4 / 28.5 / 25.6 / 28.8 in round 3's form) */
+#define ICPMI_BOUNDED_OCC 5 /* waves per SIMD the register allocation must allow.  With a slot's loads requested as a batch (SlotBatch, nn_mfma.h) and all four rounds' state live the kernel wanted ~107 registers: at 5 (96, nothing spilled) 19.8 us per C3 pass, at 6 (40 dwords spilled) 24.2, at 7 (72, more spilled) 30.4; before the batch -- every candidate's loads next to their use, sixteen dependent trips per wave -- 7 was the best (22.1).  Round by round (one round's query, distances and indices live: 75 registers) it fits 7 without spills, and measures 19.3 at 5 or 6, 19.9 at 7, 22.0 at 8: 5 stays (scripts/ab_kernels.sh, same box) */
 #endif
 __global__ __launch_bounds__(64 * kResolveWW) __attribute__((amdgpu_waves_per_eu(ICPMI_BOUNDED_OCC, 8))) void k_nn_resolve_bounded(
     const double *__restrict__ qry, int n, const double *__restrict__ sorted, const unsigned *__restrict__ perm, int m, int ms,
