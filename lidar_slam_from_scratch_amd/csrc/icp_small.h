@@ -133,8 +133,6 @@ __global__ __launch_bounds__(kSmallThreads) void k_icp_small(
         bf16x8 afrag;
         float pn;
         {
-            uint4 *rows = scratch[wave];
-            const int ql = lane & 31;
             const float fx = (float)(px - frames[s].c[0]), fy = (float)(py - frames[s].c[1]), fz = (float)(pz - frames[s].c[2]);
             unsigned xh, xm, yh, ym, zh, zm;
             split2(fx, xh, xm);
@@ -147,11 +145,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_icp_small(
             const unsigned pnh = __float_as_uint(pn) >> 16;
             pn -= __uint_as_float(pnh << 16);
             const unsigned one = 0x3f80u;
-            rows[ql * 2 + 0] = make_uint4(xh | (xh << 16), xm | (xm << 16), yh | (yh << 16), ym | (ym << 16));
-            rows[ql * 2 + 1] = make_uint4(zh | (zh << 16), zm | (zm << 16), one | (one << 16), one | (pnh << 16));
-            __builtin_amdgcn_wave_barrier();
-            afrag = __builtin_bit_cast(bf16x8, rows[ql * 2 + (lane >> 5)]);
-            __builtin_amdgcn_wave_barrier();
+            // (lanes l and l + 32 formed the same row: the lower keeps its first half, the upper its second -- the MFMA's A
+            // fragment, without the trip through LDS it took until round 4)
+            const uint4 u0 = make_uint4(xh | (xh << 16), xm | (xm << 16), yh | (yh << 16), ym | (ym << 16));
+            const uint4 u1 = make_uint4(zh | (zh << 16), zm | (zm << 16), one | (one << 16), one | (pnh << 16));
+            afrag = __builtin_bit_cast(bf16x8, lane < 32 ? u0 : u1);
         }
         ICPMI_SMALL_STAMP(1); // state, rows and the unit's operands here, A built
         f32x16 mn;

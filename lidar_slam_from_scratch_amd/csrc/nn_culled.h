@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4
         if (nchunk == 0) stamp[8] = (unsigned long long)s | ((unsigned long long)__popcll(__ballot(active)) << 32);
 #endif
         coarse_unit_rows<2, kCoarseQT, WAVES, QSOA>(lds, g * kGroupRows, active, s, nsplits, qry, n, qstride, Bpack, frames, nullptr, nullptr,
-                                                    kl, 0, gb);
+                                                    kl, 0, gb, false /* operands behind the A build: measured, nn_mfma.h */);
         __syncthreads(); // the epilogue's LDS is the next chunk's operand buffer; everybody has read next_chunk
 #ifdef ICPMI_GROUPS_CLOCKS
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

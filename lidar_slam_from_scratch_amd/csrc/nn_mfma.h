@@ -564,15 +564,23 @@ __device__ __forceinline__ void coarse_build_a(uint4 *rows, const int lane, cons
         pn[gq] -= __uint_as_float(pnh << 16);
         const unsigned one = 0x3f80u;
         // slots: x: h h m m, y: h h m m | z: h h m m, 1 1 1 |P|^2
-        rows[ql * 2 + 0] = make_uint4(xh | (xh << 16), xm | (xm << 16), yh | (yh << 16), ym | (ym << 16));
-        rows[ql * 2 + 1] = make_uint4(zh | (zh << 16), zm | (zm << 16), one | (one << 16), one | (pnh << 16));
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int t = 0; t < (QT == 1 ? 1 : 2); ++t) {
-            const uint4 f = rows[(t * 32 + (lane & 31)) * 2 + (lane >> 5)];
-            afrag[gq * 2 + t] = __builtin_bit_cast(bf16x8, f);
+        uint4 u0 = make_uint4(xh | (xh << 16), xm | (xm << 16), yh | (yh << 16), ym | (ym << 16));
+        uint4 u1 = make_uint4(zh | (zh << 16), zm | (zm << 16), one | (one << 16), one | (pnh << 16));
+        // The MFMA's A fragment of tile t: lane l < 32 holds the first half (u0) of row 32 t + l, lane l >= 32 the second
+        // (u1) of row 32 t + l - 32.  Row r was just formed by lane r, so tile 0 = [u0 of the lower half-wave | u1 of the
+        // lower half-wave], tile 1 = [u0 of the upper | u1 of the upper]: exactly what v_permlane32_swap leaves in its two
+        // operands (it exchanges the first's upper half with the second's lower half).  Until round 4 the rows went
+        // through the workgroup's LDS buffer and back -- which also kept that buffer from being filled meanwhile.
+        (void)rows;
+        if (QT == 1) { // (both half-waves formed the same 32 rows: each lane keeps the half it needs)
+            afrag[0] = __builtin_bit_cast(bf16x8, lane < 32 ? u0 : u1);
+        } else {
+#define ICPMI_SWAP_HALVES(A, B) { const auto r_ = __builtin_amdgcn_permlane32_swap((A), (B), false, false); (A) = r_[0]; (B) = r_[1]; }
+            ICPMI_SWAP_HALVES(u0.x, u1.x) ICPMI_SWAP_HALVES(u0.y, u1.y) ICPMI_SWAP_HALVES(u0.z, u1.z) ICPMI_SWAP_HALVES(u0.w, u1.w)
+#undef ICPMI_SWAP_HALVES
+            afrag[gq * 2 + 0] = __builtin_bit_cast(bf16x8, u0);
+            afrag[gq * 2 + 1] = __builtin_bit_cast(bf16x8, u1);
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -711,7 +719,8 @@ __device__ __forceinline__ void coarse_unit_rows(uint4 *lds, const int q0, const
                                                  const SplitFrame *__restrict__ frames,
                                                  float2 *__restrict__ coarse, float *__restrict__ slotmin,
                                                  const KnnLists kl = KnnLists{nullptr, nullptr, nullptr, nullptr, 0}, const int bx = 0,
-                                                 const int q0b = -1 /* >= 0: the wave's second tile starts there (coarse_build_a) */)
+                                                 const int q0b = -1 /* >= 0: the wave's second tile starts there (coarse_build_a) */,
+                                                 const bool early_stage = true /* the first chunk of operands requested before the rows */)
 {
     constexpr int THREADS = 64 * WAVES;
     constexpr int CHUNK16 = kChunkTiles * 64;  // uint4 per staged chunk (32 KiB)
@@ -725,6 +734,34 @@ __device__ __forceinline__ void coarse_unit_rows(uint4 *lds, const int q0, const
         rk0 = __builtin_amdgcn_s_memrealtime();
     }
 #endif
+    // B operands: 2 chunks of 32 tiles through one 32 KiB LDS buffer, by LDS DMA (global_load_lds_dwordx4: a wave's 64
+    // 16-byte pieces land at consecutive LDS slots, no register in between).  With `early_stage` the FIRST chunk is requested
+    // here, before the rows are even loaded -- it depends on the split alone, and since the A operands no longer pass through
+    // this buffer (coarse_build_a) nothing else needs it: as the code stood -- rows, A operands, barrier, THEN the chunk's
+    // loads into registers and on to LDS -- a unit began with two dependent round trips.  Same box, C3 (scripts/ab_kernels.sh):
+    // the grid kernels (one unit per workgroup) 299.3 -> 291.7 us with it, 296-299 with the DMA behind the A operands, 299.7
+    // with the permlane A build alone; the culled kernel (a workgroup walks over several chunks) 37.1 -> 38.4 with it and
+    // 37.2 with the DMA behind the A operands: k_nn_coarse_groups passes false.
+#if defined(ICPMI_TIMING_B0) /* timing experiment only (WRONG results): every unit reads split 0's operands -- what L2 misses on them cost */
+    const uint4 *src = Bpack;
+#else
+    const uint4 *src = Bpack + (size_t)s * (kSplitTiles * 64);
+#endif
+#ifndef ICPMI_COARSE_DMA
+#define ICPMI_COARSE_DMA 1 /* 1: LDS DMA; 0: through registers (A/B) */
+#endif
+#ifndef ICPMI_COARSE_DMA_EARLY
+#define ICPMI_COARSE_DMA_EARLY 1 /* 1: the first chunk requested before the rows; 0: behind the A operands as before (A/B) */
+#endif
+    auto stage = [&](const int chunk) {
+#pragma unroll
+        for (int e = 0; e < CHUNK16 / THREADS; ++e) {
+            if (ICPMI_COARSE_DMA)
+                __builtin_amdgcn_global_load_lds(src + (size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS, lds + e * THREADS + wave * 64, 16, 0, 0);
+            else lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
+        }
+    };
+    if (ICPMI_COARSE_DMA_EARLY && early_stage) stage(0);
     const double c0 = frames[s].c[0], c1 = frames[s].c[1], c2 = frames[s].c[2];
 
     bf16x8 afrag[QT];
@@ -761,18 +798,13 @@ __device__ __forceinline__ void coarse_unit_rows(uint4 *lds, const int q0, const
 #elif defined(ICPMI_COARSE_PRIO) && ICPMI_COARSE_PRIO == 2
     if (wave & 1) __builtin_amdgcn_s_setprio(1);
 #endif
-    // B operands: 2 chunks of 32 tiles through one 32 KiB LDS buffer
-#if defined(ICPMI_TIMING_B0) /* timing experiment only (WRONG results): every unit reads split 0's operands -- what L2 misses on them cost */
-    const uint4 *src = Bpack;
-#else
-    const uint4 *src = Bpack + (size_t)s * (kSplitTiles * 64);
-#endif
 #pragma unroll 1
     for (int chunk = 0; chunk < kSplitTiles / kChunkTiles; ++chunk) {
-        __syncthreads(); // A rows / previous chunk no longer needed
-#pragma unroll
-        for (int e = 0; e < CHUNK16 / THREADS; ++e)
-            lds[threadIdx.x + e * THREADS] = src[(size_t)chunk * CHUNK16 + threadIdx.x + e * THREADS];
+        if (chunk > 0 || !(ICPMI_COARSE_DMA_EARLY && early_stage)) {
+            if (chunk > 0) __syncthreads(); // the previous chunk is no longer needed
+            stage(chunk);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces have landed
         __syncthreads();
         if (active) coarse_tiles<QT, kChunkTiles>(lds, lane, afrag, m, zero);
     }
