@@ -618,12 +618,18 @@ __device__ __forceinline__ void coarse_epilogue(float *sc, const int lane, const
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         float thr_q = 0.f;
-        if (MODE == 2) thr_q = __shfl(thr[t >> 1], (t & 1) * 32 + ql, 64); // (formed lane-per-query like pn)
+        // (formed lane-per-query like pn: the value of lane (t & 1) * 32 + ql = the lane's own or its partner's in the other
+        // half-wave -- a v_permlane32_swap, not an LDS crossbar trip
+        // -- fetched by EVERY lane before the select: inside one arm of a conditional expression the swap would run with
+        // half the wave masked off)
+        const float thr_o = MODE == 2 ? lane_xor<32>(thr[t >> 1]) : 0.f;
+        if (MODE == 2) thr_q = half == (t & 1) ? thr[t >> 1] : thr_o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + ql] = m[t][r];
         __builtin_amdgcn_wave_barrier();
         float v[16];
-        const float pnq = __shfl(pn[t >> 1], (t & 1) * 32 + ql, 64);
+        const float pn_o = lane_xor<32>(pn[t >> 1]);
+        const float pnq = half == (t & 1) ? pn[t >> 1] : pn_o;
         {
             const float4 *rowp = reinterpret_cast<const float4 *>(sc + ql * 36 + half * 16);
 #pragma unroll
