@@ -459,7 +459,11 @@ __device__ inline void ldlt6_solve_wave(const double *sums27, double *xout, int 
 // differ in the last place here; the parity tolerance on poses (1e-9) is nine orders above that.
 __device__ __forceinline__ void sincos_step(double a, double *s, double *c)
 {
+#ifdef ICPMI_SINCOS_LIBRARY /* A/B: the device library's sincos at every angle */
+    if (false) {
+#else
     if (a < 0.78539816339744828) {
+#endif
         const double z = a * a;
         {
             const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
